@@ -1,0 +1,16 @@
+"""bundleadjustment.jl_amd -- MI355X (gfx950) implementation of the hot path of CelestineAngla/BundleAdjustment.jl:
+reprojection residual, hand-derived Jacobian and the Levenberg-Marquardt step, behind the reference's
+NLPModels-style surface.  The compute lives in libba_hip.so (csrc/, C ABI in include/ba_hip.h); this package is the
+host-side mirror of the reference interface.  The directory name contains a dot, so it is loaded through
+`__graft_entry__.load_package()` (importlib) under the module name `bundleadjustment_jl_amd`.
+"""
+from . import _lib
+from ._lib import BAError, SQDException, device_count
+from .lm import GenericExecutionStats, Levenberg_Marquardt, lm_step
+from .model import BALNLPModel, FeasibilityResidual
+from .readfiles import name, readfile
+from . import synthetic
+from . import parallel
+
+__all__ = ["BALNLPModel", "FeasibilityResidual", "Levenberg_Marquardt", "GenericExecutionStats", "readfile", "name",
+           "BAError", "SQDException", "device_count", "synthetic", "parallel", "lm_step"]

@@ -1,0 +1,147 @@
+// Internal declarations shared by the translation units of libba_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ba_hip.h"
+
+void ba_set_error(const char *fmt, ...);
+
+#define BA_HIP_CHECK(expr)                                                                          \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      ba_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));            \
+      return BA_ERR_HIP;                                                                            \
+    }                                                                                               \
+  } while (0)
+
+#define BA_CHECK(expr)            \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != BA_OK) return _rc; \
+  } while (0)
+
+// ---- dense reduced-camera system ------------------------------------------------------------------
+// S is stored as the lower block triangle of NB x NB tiles, tile (i,j), j<=i, at tile index
+// i(i+1)/2 + j, each tile contiguous row-major (128 KiB).  One all-reduce over [0, ntiles*NB*NB)
+// therefore moves exactly the lower triangle.
+constexpr int NB = 128;
+__host__ __device__ inline int64_t tile_index(int64_t i, int64_t j) { return i * (i + 1) / 2 + j; }
+
+enum ProfClass {
+  PC_RESIDUAL = 0,
+  PC_JAC_STRUCTURE,
+  PC_JAC_COORD,
+  PC_POINT_BLOCKS,
+  PC_CAM_BLOCKS,
+  PC_SCHUR_PREP,
+  PC_SCHUR_S,
+  PC_SCHUR_RHS,
+  PC_LDL_DIAG,
+  PC_LDL_TRSM,
+  PC_LDL_SYRK,
+  PC_SOLVE,
+  PC_BACKSUB,
+  PC_TRIAL,
+  PC_REDUCE,
+  PC_COMM,
+  PC_COUNT
+};
+extern const char *const kProfNames[PC_COUNT];
+
+struct ProfSlot {
+  double ms = 0;
+  int64_t calls = 0;
+};
+
+struct DenseLDL {  // workspace of the blocked LDL^T, n = 9*ncams padded to nt*NB
+  int64_t n = 0, nt = 0;
+  double *S = nullptr;     // packed lower tiles (may alias the caller's reduce buffer)
+  double *V = nullptr;     // nt tiles: V_i = L_ik * D_k of the current panel
+  double *Linv = nullptr;  // nt tiles: inverse of each unit-lower diagonal tile
+  double *D = nullptr;     // nt*NB pivots
+  int *flag = nullptr;     // device int: set to 1 on an exactly zero pivot
+  bool own_S = true;
+};
+
+struct ba_problem {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t ncams = 0, npnts = 0, nobs = 0;
+  // device mirrors (0-based int32)
+  int *cam0 = nullptr, *pnt0 = nullptr;
+  double *pt2d = nullptr;
+  float *pt2d_f32 = nullptr;
+  // observation lists sorted by point / by camera (stable) for the deterministic reductions
+  int *pt_ptr = nullptr, *pt_obs = nullptr;    // npnts+1, nobs
+  int *cam_ptr = nullptr, *cam_obs = nullptr;  // ncams+1, nobs
+  bool point_sorted = false;                   // observations already grouped by point (BAL order)
+  std::vector<int> h_cam0, h_pnt0, h_pt_ptr, h_pt_obs;
+  // scratch for the host-pointer entries
+  void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[4] = {0, 0, 0, 0};
+  // LM workspace (allocated at the first solve)
+  struct LMWork *lm = nullptr;
+  // communication (multi-GPU)
+  int rank = 0, world = 1;
+  double *reduce_buf = nullptr;
+  int64_t reduce_doubles = 0;
+  ba_allreduce_fn allreduce = nullptr;
+  void *allreduce_ctx = nullptr;
+  // profiling
+  bool prof_on = false;
+  ProfSlot prof[PC_COUNT];
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// RAII-less helper: times one kernel class with an event pair when profiling is on (synchronises).
+struct ProfScope {
+  ba_problem *p;
+  int cls;
+  hipStream_t st;
+  ProfScope(ba_problem *p_, int cls_, hipStream_t st_) : p(p_), cls(cls_), st(st_) {
+    if (p->prof_on) (void)hipEventRecord(p->ev0, st);
+  }
+  ~ProfScope() {
+    if (p->prof_on) {
+      (void)hipEventRecord(p->ev1, st);
+      (void)hipEventSynchronize(p->ev1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, p->ev0, p->ev1);
+      p->prof[cls].ms += ms;
+      p->prof[cls].calls += 1;
+    }
+  }
+};
+
+int ba_scratch(ba_problem *p, int slot, size_t bytes, void **out);
+
+// ---- launchers (ba_model_kernels.hip) -----------------------------------------------------------
+int launch_residual_f64(ba_problem *p, const double *d_x, double *d_r, hipStream_t st);
+int launch_residual_f32(ba_problem *p, const float *d_x, float *d_r, hipStream_t st);
+int launch_jac_structure(ba_problem *p, int64_t *d_rows, int64_t *d_cols, hipStream_t st);
+int launch_jac_coord_f64(ba_problem *p, const double *d_x, double *d_vals, hipStream_t st);
+int launch_jac_coord_f32(ba_problem *p, const float *d_x, float *d_vals, hipStream_t st);
+
+// ---- launchers (ba_normal_kernels.hip) ----------------------------------------------------------
+// point side: H_pp (6/pt: xx,xy,xz,yy,yz,zz) and g_p (3/pt) from J, r.  Either output may be null.
+int launch_point_blocks(ba_problem *p, const double *d_J, const double *d_r, double *d_Hpp, double *d_gp,
+                        hipStream_t st);
+// camera side: H_cc (45/cam packed lower row-major) and g_c (9/cam).  Either output may be null.
+int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, double *d_Hcc, double *d_gc,
+                      hipStream_t st);
+
+// ---- dense LDL^T (ba_dense_ldl.hip) ---------------------------------------------------------------
+int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S);
+void dense_ldl_free(DenseLDL *w);
+int64_t dense_ldl_tiles_doubles(int64_t n_unpadded);
+// factor S in place (L below the diagonal tiles' diagonal, D separately); *zero_pivot set on exact zero pivot
+int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot);
+// solve S x = b for one right-hand side held in d_b (length nt*NB, overwritten by x)
+int dense_ldl_solve(ba_problem *p, DenseLDL *w, double *d_b, hipStream_t st);
+
+// ---- LM (ba_lm.hip) ---------------------------------------------------------------------------------
+void lm_free(ba_problem *p);

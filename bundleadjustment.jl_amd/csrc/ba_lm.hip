@@ -1,0 +1,528 @@
+// Levenberg-Marquardt controller (host) over the device kernels.
+//
+// Control flow, constants and stopping tests follow the reference line by line:
+//   variant 1: src/lm.jl:15-418            (lambda0 = max(lambda, 1e10/|J'r|), ared >= 1e-4 pred, line search)
+//   variant 0: src/LevenbergMarquardt.jl:16-385 (what src/solve_ba.jl runs)
+// What differs is how the linear step is obtained: the reference factors the augmented matrix
+// K = [[I J];[J' -lambda I]] (src/lm.jl:68-100,154-238); here the residual rows and point columns of K are
+// eliminated in closed form on the device (ba_normal_kernels.hip) and the remaining reduced camera system is
+// factored densely on the f64 matrix cores (ba_dense_ldl.hip).  Both give (J'J + lambda I) delta = -J' r and
+// 1/2|delta_r|^2 = 1/2|J delta + r|^2 (K [dr; d] = [-r; 0]  <=>  dr = -(r + J d)), which is evaluated directly.
+//
+// One device->host copy of a handful of scalars per iteration drives the accept/reject logic, as the reference's
+// norm() calls do.  As in the reference, a rejected step only changes the damping: J, Hpp, Hcc, gp, gc are reused.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "ba_internal.h"
+#include "ba_lm_internal.h"
+
+namespace {
+
+double wall() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// scalar slots.  "sharded" sums are partial per rank and all-reduced; "replicated" ones are identical on every rank.
+// slots 0..2 are refreshed (and reduced) with the linearisation, slots 3..5 with every trial step
+enum { SH_RSQ = 0, SH_GP, SH_X_P, SH_RSQ_TRIAL, SH_MODEL, SH_DELTA_P, SH_COUNT = 8 };
+constexpr int SH_LIN_COUNT = 3, SH_TRIAL_FIRST = 3, SH_TRIAL_COUNT = 3;
+enum { RP_DELTA_C = 0, RP_X_C, RP_GC, RP_COUNT = 8 };
+
+template <typename T>
+int dmalloc(T **ptr, int64_t count) {
+  BA_HIP_CHECK(hipMalloc((void **)ptr, (size_t)(count > 0 ? count : 1) * sizeof(T)));
+  return BA_OK;
+}
+
+template <typename T>
+int upload_vec(T **d, const std::vector<T> &h) {
+  BA_CHECK(dmalloc(d, (int64_t)h.size()));
+  if (!h.empty()) BA_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return BA_OK;
+}
+
+// Build the (camera_a >= camera_b)-sorted list of observation pairs sharing a point.
+int build_tasks(ba_problem *p, SchurTasks *T) {
+  const int64_t ncams = p->ncams, npnts = p->npnts;
+  const std::vector<int> &cam = p->h_cam0, &ptr = p->h_pt_ptr, &obs = p->h_pt_obs;
+  // pass 1: tasks per camera_a
+  std::vector<int64_t> ca_ptr((size_t)ncams + 1, 0);
+  int64_t ntasks = 0;
+  for (int64_t pt = 0; pt < npnts; pt++)
+    for (int qa = ptr[(size_t)pt]; qa < ptr[(size_t)pt + 1]; qa++) {
+      int ca = cam[(size_t)obs[(size_t)qa]];
+      for (int qb = ptr[(size_t)pt]; qb < ptr[(size_t)pt + 1]; qb++)
+        if (ca >= cam[(size_t)obs[(size_t)qb]]) {
+          ca_ptr[(size_t)ca + 1]++;
+          ntasks++;
+        }
+    }
+  if (ntasks > (int64_t)2000000000) {
+    ba_set_error("Schur task list too long (%lld)", (long long)ntasks);
+    return BA_ERR_ARG;
+  }
+  for (int64_t c = 0; c < ncams; c++) ca_ptr[(size_t)c + 1] += ca_ptr[(size_t)c];
+  // pass 2: bucket by camera_a (point order preserved)
+  std::vector<int> ta((size_t)ntasks), tb((size_t)ntasks);
+  {
+    std::vector<int64_t> cur(ca_ptr.begin(), ca_ptr.end() - 1);
+    for (int64_t pt = 0; pt < npnts; pt++)
+      for (int qa = ptr[(size_t)pt]; qa < ptr[(size_t)pt + 1]; qa++) {
+        int oa = obs[(size_t)qa], ca = cam[(size_t)oa];
+        for (int qb = ptr[(size_t)pt]; qb < ptr[(size_t)pt + 1]; qb++) {
+          int ob = obs[(size_t)qb];
+          if (ca >= cam[(size_t)ob]) {
+            int64_t q = cur[(size_t)ca]++;
+            ta[(size_t)q] = oa;
+            tb[(size_t)q] = ob;
+          }
+        }
+      }
+  }
+  // pass 3: inside each camera_a bucket, stable counting sort by camera_b; emit keys (diagonal key always)
+  std::vector<int> sa((size_t)ntasks), sb((size_t)ntasks), key_ptr, key_ca, key_cb;
+  std::vector<int> cnt((size_t)ncams + 1);
+  key_ptr.push_back(0);
+  for (int64_t ca = 0; ca < ncams; ca++) {
+    const int64_t b0 = ca_ptr[(size_t)ca], b1 = ca_ptr[(size_t)ca + 1];
+    std::fill(cnt.begin(), cnt.begin() + ca + 2, 0);
+    for (int64_t q = b0; q < b1; q++) cnt[(size_t)cam[(size_t)tb[(size_t)q]] + 1]++;
+    for (int64_t cb = 0; cb <= ca; cb++) {
+      int c = cnt[(size_t)cb + 1];
+      if (c > 0 || cb == ca) {
+        key_ca.push_back((int)ca);
+        key_cb.push_back((int)cb);
+        key_ptr.push_back(key_ptr.back() + c);
+      }
+      cnt[(size_t)cb + 1] += cnt[(size_t)cb];
+    }
+    // cnt[cb] = offset of camera_b bucket inside [b0, b1)
+    for (int64_t q = b0; q < b1; q++) {
+      int cb = cam[(size_t)tb[(size_t)q]];
+      int64_t dst = b0 + cnt[(size_t)cb]++;
+      sa[(size_t)dst] = ta[(size_t)q];
+      sb[(size_t)dst] = tb[(size_t)q];
+    }
+  }
+  T->nkeys = (int64_t)key_ca.size();
+  T->ntasks = ntasks;
+  BA_CHECK(upload_vec(&T->key_ptr, key_ptr));
+  BA_CHECK(upload_vec(&T->key_ca, key_ca));
+  BA_CHECK(upload_vec(&T->key_cb, key_cb));
+  BA_CHECK(upload_vec(&T->task_a, sa));
+  BA_CHECK(upload_vec(&T->task_b, sb));
+  return BA_OK;
+}
+
+int64_t reduce_layout(ba_problem *p, int64_t *off_rhs, int64_t *off_gc, int64_t *off_scal) {
+  const int64_t n = 9 * p->ncams;
+  const int64_t tiles = dense_ldl_tiles_doubles(n);
+  const int64_t npad = ((n + NB - 1) / NB > 0 ? (n + NB - 1) / NB : 1) * NB;
+  if (off_rhs) *off_rhs = tiles;
+  if (off_gc) *off_gc = tiles + npad;
+  if (off_scal) *off_scal = tiles + 2 * npad;
+  return tiles + 2 * npad + SH_COUNT;
+}
+
+struct LMState {
+  double *red = nullptr;  // [S tiles | rhs | gc | sharded scalars]
+  bool own_red = false;
+  int64_t off_rhs = 0, off_gc = 0, off_scal = 0, red_doubles = 0;
+  double *scal_rep = nullptr;
+  double *h_sh = nullptr, *h_rp = nullptr;  // pinned
+};
+
+}  // namespace
+
+struct LMWorkFull : LMWork {
+  LMState s;
+};
+
+static int lm_ensure(ba_problem *p) {
+  if (p->lm) return BA_OK;
+  LMWorkFull *w = new LMWorkFull();
+  p->lm = w;
+  const int64_t ncams = p->ncams, npnts = p->npnts, nobs = p->nobs;
+  w->nvar = 9 * ncams + 3 * npnts;
+  w->nequ = 2 * nobs;
+  w->n = 9 * ncams;
+  w->s.red_doubles = reduce_layout(p, &w->s.off_rhs, &w->s.off_gc, &w->s.off_scal);
+  if (p->reduce_buf) {
+    if (p->reduce_doubles < w->s.red_doubles) {
+      ba_set_error("reduce buffer too small: %lld < %lld doubles", (long long)p->reduce_doubles,
+                   (long long)w->s.red_doubles);
+      return BA_ERR_ARG;
+    }
+    w->s.red = p->reduce_buf;
+    w->s.own_red = false;
+  } else {
+    BA_CHECK(dmalloc(&w->s.red, w->s.red_doubles));
+    w->s.own_red = true;
+  }
+  BA_CHECK(dense_ldl_alloc(&w->ldl, w->n, w->s.red));
+  w->npad = w->ldl.n;
+  w->rhs = w->s.red + w->s.off_rhs;
+  w->gc = w->s.red + w->s.off_gc;
+  w->scal = w->s.red + w->s.off_scal;
+  BA_HIP_CHECK(hipMemset(w->s.red + w->s.off_rhs, 0, (size_t)(w->s.red_doubles - w->s.off_rhs) * sizeof(double)));
+  BA_CHECK(dmalloc(&w->x, w->nvar));
+  BA_CHECK(dmalloc(&w->x_trial, w->nvar));
+  BA_CHECK(dmalloc(&w->delta, w->nvar));
+  BA_CHECK(dmalloc(&w->r, w->nequ));
+  BA_CHECK(dmalloc(&w->r_trial, w->nequ));
+  BA_CHECK(dmalloc(&w->J, 24 * nobs));
+  BA_CHECK(dmalloc(&w->Hpp, 6 * npnts));
+  BA_CHECK(dmalloc(&w->gp, 3 * npnts));
+  BA_CHECK(dmalloc(&w->Uinv, 6 * npnts));
+  BA_CHECK(dmalloc(&w->u, 3 * npnts));
+  BA_CHECK(dmalloc(&w->Hcc, 45 * ncams));
+  BA_CHECK(dmalloc(&w->partial, (int64_t)RED_BLOCKS));
+  BA_CHECK(dmalloc(&w->s.scal_rep, (int64_t)RP_COUNT));
+  BA_HIP_CHECK(hipHostMalloc((void **)&w->s.h_sh, SH_COUNT * sizeof(double)));
+  BA_HIP_CHECK(hipHostMalloc((void **)&w->s.h_rp, RP_COUNT * sizeof(double)));
+  BA_CHECK(build_tasks(p, &w->tasks));
+  return BA_OK;
+}
+
+void lm_free(ba_problem *p) {
+  if (!p->lm) return;
+  LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
+  dense_ldl_free(&w->ldl);
+  void *ptrs[] = {w->x, w->x_trial, w->delta, w->r, w->r_trial, w->J, w->Hpp, w->gp, w->Uinv, w->u, w->Hcc,
+                  w->partial, w->colscale, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
+                  w->tasks.task_a, w->tasks.task_b, w->s.own_red ? w->s.red : nullptr};
+  for (void *q : ptrs)
+    if (q) (void)hipFree(q);
+  if (w->s.h_sh) (void)hipHostFree(w->s.h_sh);
+  if (w->s.h_rp) (void)hipHostFree(w->s.h_rp);
+  delete w;
+  p->lm = nullptr;
+}
+
+// all-reduce [off, off+count) of the reduce buffer over the ranks (no-op on one GPU)
+static int comm_sum(ba_problem *p, LMWorkFull *w, int64_t off, int64_t count, hipStream_t st) {
+  if (p->world <= 1 || !p->allreduce) return BA_OK;
+  ProfScope ps(p, PC_COMM, st);
+  int rc = p->allreduce(p->allreduce_ctx, off, count, (void *)st);
+  if (rc != 0) {
+    ba_set_error("all-reduce hook failed (%d)", rc);
+    return BA_ERR_COMM;
+  }
+  return BA_OK;
+}
+
+// r, J and the normal-equation blocks at w->x; fills sharded/replicated scalars RSQ?, GP, GC, X_P, X_C
+static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too, hipStream_t st) {
+  if (residual_too) BA_CHECK(launch_residual_f64(p, w->x, w->r, st));
+  BA_CHECK(launch_sumsq(p, w->nequ, w->r, w->partial, w->scal, SH_RSQ, st));
+  BA_CHECK(launch_jac_coord_f64(p, w->x, w->J, st));
+  BA_CHECK(launch_point_blocks(p, w->J, w->r, w->Hpp, w->gp, st));
+  BA_CHECK(launch_cam_blocks(p, w->J, w->r, w->Hcc, w->gc, st));
+  BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->gp, w->partial, w->scal, SH_GP, st));
+  BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->x, w->partial, w->scal, SH_X_P, st));
+  // gc and the linearisation scalars are adjacent in the reduce buffer: one all-reduce
+  BA_CHECK(comm_sum(p, w, w->s.off_gc, w->npad + SH_LIN_COUNT, st));
+  BA_CHECK(launch_sumsq(p, w->n, w->gc, w->partial, w->s.scal_rep, RP_GC, st));
+  BA_CHECK(launch_sumsq(p, w->n, w->x + 3 * p->npnts, w->partial, w->s.scal_rep, RP_X_C, st));
+  return BA_OK;
+}
+
+static int fetch_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st) {
+  BA_HIP_CHECK(hipMemcpyAsync(w->s.h_sh, w->scal, SH_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+  BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+  BA_HIP_CHECK(hipStreamSynchronize(st));
+  return BA_OK;
+}
+
+// delta = -(J'J + lambda I)^-1 J'r at the current linearisation; also |J delta + r|^2 -> SH_MODEL, |delta|^2
+static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, hipStream_t st) {
+  // every rank holds partial Hcc / Schur sums; the lambda I of the camera block is added by rank 0 only
+  const double lam_diag = (p->rank == 0) ? lambda : 0.0;
+  BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st));
+  BA_CHECK(launch_schur_blocks(p, &w->tasks, w->J, w->Uinv, w->Hcc, lam_diag, w->ldl.S, w->n,
+                               p->rank == 0 ? w->npad : w->n, st));
+  BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
+  BA_CHECK(launch_schur_rhs(p, w->J, w->r, w->u, w->rhs, st));
+  BA_CHECK(comm_sum(p, w, 0, w->s.off_gc, st));  // S tiles and rhs are adjacent
+  int zp = 0;
+  BA_CHECK(dense_ldl_factor(p, &w->ldl, st, nullptr));
+  BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st));
+  double *dc = w->delta + 3 * p->npnts;
+  BA_HIP_CHECK(hipMemcpyAsync(dc, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->u, dc, w->delta, st));
+  (void)zp;
+  return BA_OK;
+}
+
+static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st) {
+  BA_CHECK(launch_model_sq(p, w->J, w->r, w->delta, w->partial, w->scal, SH_MODEL, st));
+  BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->delta, w->partial, w->scal, SH_DELTA_P, st));
+  BA_CHECK(launch_sumsq(p, w->n, w->delta + 3 * p->npnts, w->partial, w->s.scal_rep, RP_DELTA_C, st));
+  return BA_OK;
+}
+
+static int trial_point(ba_problem *p, LMWorkFull *w, hipStream_t st) {
+  BA_CHECK(launch_axpy(p, w->nvar, w->x, w->delta, w->x_trial, st));
+  BA_CHECK(launch_residual_f64(p, w->x_trial, w->r_trial, st));
+  BA_CHECK(launch_sumsq(p, w->nequ, w->r_trial, w->partial, w->scal, SH_RSQ_TRIAL, st));
+  return BA_OK;
+}
+
+static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
+  int h = 0;
+  BA_HIP_CHECK(hipMemcpyAsync(&h, w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  BA_HIP_CHECK(hipStreamSynchronize(st));
+  if (h) {
+    ba_set_error("reduced camera system: exactly zero pivot (SQDException in the reference)");
+    return BA_ERR_ZERO_PIVOT;
+  }
+  return BA_OK;
+}
+
+extern "C" int ba_lm_reduce_doubles(ba_problem *p, int64_t *count) {
+  if (!p || !count) return BA_ERR_ARG;
+  *count = reduce_layout(p, nullptr, nullptr, nullptr);
+  return BA_OK;
+}
+
+extern "C" int ba_lm_set_comm(ba_problem *p, int rank, int world, double *d_reduce_buf, int64_t buf_doubles,
+                              ba_allreduce_fn fn, void *ctx) {
+  if (!p || world < 1 || rank < 0 || rank >= world) return BA_ERR_ARG;
+  if (p->lm) {
+    ba_set_error("ba_lm_set_comm must be called before the first solve on this handle");
+    return BA_ERR_ARG;
+  }
+  if (world > 1 && (!fn || !d_reduce_buf)) {
+    ba_set_error("ba_lm_set_comm: world > 1 needs a reduce buffer and an all-reduce hook");
+    return BA_ERR_ARG;
+  }
+  p->rank = rank;
+  p->world = world;
+  p->reduce_buf = d_reduce_buf;
+  p->reduce_doubles = buf_doubles;
+  p->allreduce = fn;
+  p->allreduce_ctx = ctx;
+  return BA_OK;
+}
+
+extern "C" int ba_lm_step(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
+                          double *jtr) {
+  if (!p || !x || !delta) {
+    ba_set_error("ba_lm_step: null argument");
+    return BA_ERR_ARG;
+  }
+  BA_HIP_CHECK(hipSetDevice(p->device));
+  BA_CHECK(lm_ensure(p));
+  LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
+  hipStream_t st = p->stream;
+  BA_HIP_CHECK(hipMemcpyAsync(w->x, x, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
+  BA_CHECK(refresh_linearisation(p, w, true, st));
+  BA_CHECK(linear_step(p, w, lambda, st));
+  BA_CHECK(check_pivot(p, w, st));
+  BA_CHECK(step_scalars(p, w, st));
+  BA_CHECK(comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st));
+  BA_CHECK(fetch_scalars(p, w, st));
+  BA_HIP_CHECK(hipMemcpyAsync(delta, w->delta, (size_t)w->nvar * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (jtr) {
+    BA_HIP_CHECK(hipMemcpyAsync(jtr, w->gp, (size_t)3 * p->npnts * sizeof(double), hipMemcpyDeviceToHost, st));
+    BA_HIP_CHECK(hipMemcpyAsync(jtr + 3 * p->npnts, w->gc, (size_t)w->n * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  BA_HIP_CHECK(hipStreamSynchronize(st));
+  if (half_sq_model) *half_sq_model = 0.5 * w->s.h_sh[SH_MODEL];
+  return BA_OK;
+}
+
+extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, ba_lm_stats *stats, ba_log_cb cb,
+                           void *cb_ctx) {
+  if (!p || !o || !x_inout || !stats) {
+    ba_set_error("ba_lm_solve: null argument");
+    return BA_ERR_ARG;
+  }
+  if (o->variant != 0 && o->variant != 1) {
+    ba_set_error("ba_lm_solve: variant must be 0 (LevenbergMarquardt.jl) or 1 (lm.jl)");
+    return BA_ERR_ARG;
+  }
+  if (o->facto_f32) {
+    ba_set_error("ba_lm_solve: facto_type = Float32 is not implemented yet");
+    return BA_ERR_ARG;
+  }
+  BA_HIP_CHECK(hipSetDevice(p->device));
+  const double t_start = wall();
+  BA_CHECK(lm_ensure(p));
+  LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
+  hipStream_t st = p->stream;
+  const int V = o->variant;
+  // defaults: src/lm.jl:20-26 / src/LevenbergMarquardt.jl:21-26
+  const double eps = 2.220446049250313e-16, sq = std::sqrt(eps), cbr = std::pow(eps, 1.0 / 3.0);
+  const double restol = o->restol >= 0 ? o->restol : (V ? cbr : 100 * sq);
+  const double satol = o->satol >= 0 ? o->satol : sq, srtol = o->srtol >= 0 ? o->srtol : sq;
+  const double oatol = o->oatol >= 0 ? o->oatol : sq, ortol = o->ortol >= 0 ? o->ortol : (V ? cbr : 1000 * sq);
+  const double atol = o->atol >= 0 ? o->atol : (V ? sq : 100 * sq), rtol = o->rtol >= 0 ? o->rtol : (V ? cbr : 1000 * sq);
+  const double nu_d = o->nu_d > 0 ? o->nu_d : 3, nu_m = o->nu_m > 0 ? o->nu_m : 3;
+  double lambda = o->lambda > 0 ? o->lambda : (V ? 30 : 0.1);
+  const double delta_d = o->delta_d > 0 ? o->delta_d : 2;
+  const int ite_max = o->ite_max >= 0 ? o->ite_max : (V ? 200 : 100);
+  const bool linesearch = V && o->linesearch;
+
+  memset(stats, 0, sizeof *stats);
+  stats->status = BA_ST_UNKNOWN;
+  double *h_sh = w->s.h_sh, *h_rp = w->s.h_rp;
+
+  BA_HIP_CHECK(hipMemcpyAsync(w->x, x_inout, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
+  BA_CHECK(refresh_linearisation(p, w, true, st));  // r, J, J'r   (lm.jl:39-58)
+  BA_CHECK(fetch_scalars(p, w, st));
+  stats->n_residual++;
+  stats->n_jacobian++;
+  double norm_r = std::sqrt(h_sh[SH_RSQ]);
+  double obj = norm_r * norm_r / 2;
+  double norm_Jtr = std::sqrt(h_sh[SH_GP] + h_rp[RP_GC]);
+  double norm_x = std::sqrt(h_sh[SH_X_P] + h_rp[RP_X_C]);
+  if (V) lambda = std::fmax(lambda, 1e10 / norm_Jtr);  // lm.jl:59
+
+  double norm_delta = 0, dr2 = 0, ared = 0, pred = 0;
+  const double eps_first = atol + rtol * norm_Jtr;  // lm.jl:107
+  double old_obj = obj;
+  bool small_step = false, first_order = norm_Jtr < eps_first, small_residual = norm_r < restol;
+  bool small_obj_change = false, fail2 = false;
+  int iter = 0;
+  bool tired = iter > ite_max;
+  bool accepted = false;
+  int rc = BA_OK;
+  const double t_loop = wall();
+
+  while (!(small_step || first_order || small_residual || small_obj_change || tired || fail2)) {
+    if (V) iter++;                                                                           // lm.jl:127
+    if (!V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);  // LevenbergMarquardt.jl:143-147
+    if ((rc = linear_step(p, w, lambda, st)) != BA_OK) break;
+    stats->n_factor++;
+    if ((rc = step_scalars(p, w, st)) != BA_OK) break;
+    if ((rc = trial_point(p, w, st)) != BA_OK) break;  // lm.jl:251-254
+    stats->n_residual++;
+    if ((rc = comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st)) != BA_OK) break;
+    if ((rc = fetch_scalars(p, w, st)) != BA_OK) break;
+    {
+      int h = 0;
+      hipError_t e = hipMemcpy(&h, w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) {
+        ba_set_error("pivot flag copy: %s", hipGetErrorString(e));
+        rc = BA_ERR_HIP;
+        break;
+      }
+      if (h) {
+        ba_set_error("reduced camera system: exactly zero pivot (SQDException in the reference)");
+        rc = BA_ERR_ZERO_PIVOT;
+        break;
+      }
+    }
+    dr2 = 0.5 * h_sh[SH_MODEL];  // 1/2 |delta_r|^2   (lm.jl:229)
+    double obj_suiv = 0.5 * h_sh[SH_RSQ_TRIAL];
+    double norm_rsuiv = std::sqrt(h_sh[SH_RSQ_TRIAL]);
+    if (!V) iter++;  // LevenbergMarquardt.jl:240
+
+    bool step_accepted;
+    int ntimes = 0;
+    if (V) {
+      pred = obj - dr2;
+      ared = obj - obj_suiv;
+      step_accepted = ared >= 1e-4 * pred;  // lm.jl:257-259
+      while (linesearch && !step_accepted && ntimes < 4) {  // lm.jl:264-295
+        // delta /= delta_d ; delta_r = (delta_r - r)/delta_d (lm.jl:277) is again -(J delta + r) for the new delta
+        if ((rc = launch_scale_scalar(p, w->nvar, w->delta, 1.0 / delta_d, st)) != BA_OK) break;
+        if ((rc = step_scalars(p, w, st)) != BA_OK) break;
+        if ((rc = trial_point(p, w, st)) != BA_OK) break;
+        stats->n_residual++;
+        if ((rc = comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st)) != BA_OK) break;
+        if ((rc = fetch_scalars(p, w, st)) != BA_OK) break;
+        dr2 = 0.5 * h_sh[SH_MODEL];
+        obj_suiv = 0.5 * h_sh[SH_RSQ_TRIAL];
+        norm_rsuiv = std::sqrt(h_sh[SH_RSQ_TRIAL]);
+        pred = obj - dr2;
+        ared = obj - obj_suiv;
+        step_accepted = ared >= 1e-4 * pred;
+        ntimes++;
+      }
+      if (rc != BA_OK) break;
+    } else {
+      step_accepted = (obj_suiv - obj) < 1e-4 * (dr2 - obj);  // LevenbergMarquardt.jl:243
+    }
+    accepted = step_accepted;
+    const double nd = std::sqrt(h_sh[SH_DELTA_P] + h_rp[RP_DELTA_C]);
+
+    if (V) {
+      norm_delta = nd;  // lm.jl:297-302
+      if (std::isnan(norm_delta)) {
+        fail2 = true;
+        continue;
+      }
+      if (cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, ared / pred,
+                 (step_accepted && dr2 <= obj) ? 1 : 0);  // lm.jl:304
+      if (o->verbose)
+        fprintf(stderr, "%6d %14.7e %10.2e %10.2e %10.2e %10.2e %10.2e %s\n", iter, obj, old_obj - obj, norm_Jtr, lambda,
+                norm_delta, ared / pred, (step_accepted && dr2 <= obj) ? "acc" : "rej");
+    }
+
+    if (!step_accepted) {
+      stats->n_rejected++;
+      if (V) lambda = std::fmax(lambda, 1 / norm_delta) * std::pow(nu_m, (double)(ntimes + 1));  // lm.jl:308
+      else lambda *= nu_m;                                                                          // LevenbergMarquardt.jl:269
+    } else {
+      stats->n_accepted++;
+      if (V) {  // lm.jl:329-337
+        if (ntimes > 0) lambda /= std::pow(nu_d, (double)(ntimes - 1));
+        else lambda /= nu_d;
+        if (ared >= 0.9 * pred) lambda /= nu_d;
+        lambda = std::fmax(1.0e-8, lambda);
+      } else {
+        lambda /= nu_d;  // LevenbergMarquardt.jl:292
+      }
+      std::swap(w->x, w->x_trial);  // x .= x_suiv
+      std::swap(w->r, w->r_trial);  // r .= r_suiv
+      old_obj = obj;
+      norm_r = norm_rsuiv;
+      obj = obj_suiv;
+      if ((rc = refresh_linearisation(p, w, false, st)) != BA_OK) break;  // J, J'r  (lm.jl:341,370)
+      stats->n_jacobian++;
+      if ((rc = fetch_scalars(p, w, st)) != BA_OK) break;
+      norm_Jtr = std::sqrt(h_sh[SH_GP] + h_rp[RP_GC]);
+      norm_x = std::sqrt(h_sh[SH_X_P] + h_rp[RP_X_C]);
+      if (!V) norm_delta = nd;  // LevenbergMarquardt.jl:352
+      small_step = norm_delta < satol + srtol * norm_x;  // lm.jl:375-379
+      first_order = norm_Jtr < eps_first;
+      small_residual = norm_r < restol;
+      small_obj_change = (old_obj - obj) < oatol + ortol * old_obj;
+    }
+    if (!V && o->verbose)
+      fprintf(stderr, "%6d %14.7e %10.2e %10.2e %10.2e %10.2e %10.2e %s\n", iter, obj, old_obj - obj, norm_Jtr, lambda, nd,
+              dr2, step_accepted ? "true" : "false");
+    tired = iter > ite_max;  // lm.jl:382
+  }
+  if (rc == BA_OK && !V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);
+  stats->loop_s = wall() - t_loop;
+
+  if (rc != BA_OK) {
+    stats->status = BA_ST_EXCEPTION;
+  } else if (small_step) stats->status = BA_ST_SMALL_STEP;  // lm.jl:391-405
+  else if (first_order) stats->status = BA_ST_FIRST_ORDER;
+  else if (small_residual) stats->status = BA_ST_SMALL_RESIDUAL;
+  else if (small_obj_change) stats->status = BA_ST_ACCEPTABLE;
+  else if (fail2) stats->status = BA_ST_EXCEPTION;
+  else if (tired) stats->status = BA_ST_MAX_ITER;
+  stats->iter = iter;
+  stats->objective = obj;
+  stats->dual_feas = norm_Jtr;
+  stats->lambda_final = lambda;
+  {
+    hipError_t e = hipMemcpyAsync(x_inout, w->x, (size_t)w->nvar * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess && rc == BA_OK) {
+      ba_set_error("solution copy: %s", hipGetErrorString(e));
+      rc = BA_ERR_HIP;
+    }
+  }
+  stats->elapsed_s = wall() - t_start;
+  return rc;  // a NaN step is not an error of the call: status :exception, as in the reference (lm.jl:297-302,401-402)
+}

@@ -1,0 +1,48 @@
+// Internal: LM workspace and launchers of the normal-equation kernels.
+#pragma once
+#include "ba_internal.h"
+
+constexpr int RED_BLOCKS = 1024;  // fixed number of partial sums => fixed summation tree
+
+// Schur task list (built once per problem on the host): all ordered observation pairs (a, b) of one point with
+// camera(a) >= camera(b), sorted by (camera(a), camera(b)); key k owns tasks [key_ptr[k], key_ptr[k+1]).
+// Every camera has its diagonal key even when it has no observation.
+struct SchurTasks {
+  int64_t nkeys = 0, ntasks = 0;
+  int *key_ptr = nullptr, *key_ca = nullptr, *key_cb = nullptr;  // device
+  int *task_a = nullptr, *task_b = nullptr;                       // device
+};
+
+// scalar slots of LMWork::scal (device) / h_scal (pinned host)
+enum { SC_RSQ = 0, SC_RSQ_TRIAL, SC_MODEL, SC_DELTA, SC_XSQ, SC_JTR, SC_COUNT = 8 };
+
+struct LMWork {
+  int64_t nvar = 0, nequ = 0, n = 0, npad = 0;  // n = 9*ncams
+  double *x = nullptr, *x_trial = nullptr, *delta = nullptr;
+  double *r = nullptr, *r_trial = nullptr, *J = nullptr;
+  double *Hpp = nullptr, *gp = nullptr, *Uinv = nullptr, *u = nullptr;
+  double *Hcc = nullptr, *gc = nullptr;  // gc: 9*ncams
+  double *rhs = nullptr;                 // npad
+  double *colscale = nullptr;            // nvar (normalize != None)
+  double *partial = nullptr;             // RED_BLOCKS
+  double *scal = nullptr;                // SC_COUNT device scalars
+  double *h_scal = nullptr;              // pinned host mirror
+  SchurTasks tasks;
+  DenseLDL ldl;
+};
+
+int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const double *d_gp, double *d_Uinv,
+                      double *d_u, hipStream_t st);
+int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv,
+                        const double *d_Hcc, double lambda, double *d_S, int64_t n, int64_t npad, hipStream_t st);
+int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
+                     hipStream_t st);
+int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,
+                   double *d_dp, hipStream_t st);
+int launch_model_sq(ba_problem *p, const double *d_J, const double *d_r, const double *d_delta, double *d_partial,
+                    double *d_scal, int slot, hipStream_t st);
+int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial, double *d_scal, int slot,
+                 hipStream_t st);
+int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st);
+int launch_scale_scalar(ba_problem *p, int64_t n, double *d_v, double alpha, hipStream_t st);
+int launch_scale_vec(ba_problem *p, int64_t n, const double *d_s, double *d_v, int divide, hipStream_t st);

@@ -1,0 +1,450 @@
+// Normal-equation kernels of the Levenberg-Marquardt step (gfx950).
+//
+// The reference assembles K = [[I J];[J' -lambda I]] with sparse() every iteration and factors it with a
+// scalar sparse LDL' (src/lm.jl:68-100,154-238; src/ldl_aux.jl:122-201).  Eliminating the residual rows and
+// then the point columns of K in closed form gives the reduced camera system
+//     S dc = rhs,  S = Hcc + lambda I - sum_p W_p' U_p^-1 W_p,  U_p = Hpp[p] + lambda I,
+//     rhs = -(gc - sum_p W_p' U_p^-1 gp[p]),  dp = -U_p^-1 (gp + W_p dc)
+// which is what these kernels build.  With the 2x12 block of observation a written [A_a | B_a]
+// (A_a 2x3 point part, B_a 2x9 camera part):  W_a = A_a' B_a  and
+//     W_a' U^-1 W_b = B_a' (A_a U^-1 A_b') B_b = B_a' Q_ab B_b     with Q_ab only 2x2,
+// so nothing but J itself (24 doubles / observation, the jac_coord! layout) is ever stored.
+//
+// All sums are deterministic: point-side sums run over the point-sorted observation list (one lane per
+// point), camera-side sums over the camera-sorted list (one workgroup per camera, fixed tree), the Schur
+// blocks over a (camera_a, camera_b)-sorted task list (one wave per 9x9 block).  No float atomics.
+#include "ba_internal.h"
+#include "ba_lm_internal.h"
+
+namespace {
+
+constexpr int BLK = 256;
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ---- point side: Hpp (xx,xy,xz,yy,yz,zz) and gp = A' r ------------------------------------------------
+__global__ __launch_bounds__(BLK) void k_point_blocks(int64_t npnts, const int *__restrict__ pt_ptr,
+                                                       const int *__restrict__ pt_obs, const double *__restrict__ J,
+                                                       const double *__restrict__ r, double *__restrict__ Hpp,
+                                                       double *__restrict__ gp) {
+  int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= npnts) return;
+  double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (int q = pt_ptr[p]; q < pt_ptr[p + 1]; q++) {
+    int64_t o = pt_obs[q];
+    const double *Jo = J + 24 * o;
+    double a0[3] = {Jo[0], Jo[1], Jo[2]}, a1[3] = {Jo[12], Jo[13], Jo[14]};
+    h[0] += a0[0] * a0[0] + a1[0] * a1[0];
+    h[1] += a0[0] * a0[1] + a1[0] * a1[1];
+    h[2] += a0[0] * a0[2] + a1[0] * a1[2];
+    h[3] += a0[1] * a0[1] + a1[1] * a1[1];
+    h[4] += a0[1] * a0[2] + a1[1] * a1[2];
+    h[5] += a0[2] * a0[2] + a1[2] * a1[2];
+    if (gp) {
+      double r0 = r[2 * o], r1 = r[2 * o + 1];
+      g[0] += a0[0] * r0 + a1[0] * r1;
+      g[1] += a0[1] * r0 + a1[1] * r1;
+      g[2] += a0[2] * r0 + a1[2] * r1;
+    }
+  }
+  if (Hpp)
+    for (int i = 0; i < 6; i++) Hpp[6 * p + i] = h[i];
+  if (gp)
+    for (int i = 0; i < 3; i++) gp[3 * p + i] = g[i];
+}
+
+// ---- camera side: one workgroup per camera, fixed-order tree ----------------------------------------------
+// MODE 0: Hcc (45, packed lower row-major) and gc = B' r (9).   MODE 1: gc only.
+// MODE 2: rhs = sum_a B_a' (A_a u_p(a) - r_a)   (u = U^-1 gp per point).
+template <int MODE>
+__global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_ptr, const int *__restrict__ cam_obs,
+                                                     const int *__restrict__ pnt0, const double *__restrict__ J,
+                                                     const double *__restrict__ r, const double *__restrict__ u,
+                                                     double *__restrict__ Hcc, double *__restrict__ out9) {
+  constexpr int NACC = (MODE == 0) ? 54 : 9;
+  __shared__ double red[BLK / 64][NACC];
+  const int c = blockIdx.x;
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; i++) acc[i] = 0;
+  for (int q = cam_ptr[c] + threadIdx.x; q < cam_ptr[c + 1]; q += BLK) {
+    int64_t o = cam_obs[q];
+    const double *Jo = J + 24 * o;
+    double b0[9], b1[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      b0[i] = Jo[3 + i];
+      b1[i] = Jo[15 + i];
+    }
+    double w0, w1;
+    if (MODE == 2) {
+      const double *up = u + 3 * (int64_t)pnt0[o];
+      w0 = (Jo[0] * up[0] + Jo[1] * up[1] + Jo[2] * up[2]) - r[2 * o];
+      w1 = (Jo[12] * up[0] + Jo[13] * up[1] + Jo[14] * up[2]) - r[2 * o + 1];
+    } else {
+      w0 = r[2 * o];
+      w1 = r[2 * o + 1];
+    }
+    if (MODE == 0) {
+      int idx = 0;
+#pragma unroll
+      for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) acc[idx++] += b0[i] * b0[j] + b1[i] * b1[j];
+#pragma unroll
+      for (int i = 0; i < 9; i++) acc[45 + i] += b0[i] * w0 + b1[i] * w1;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; i++) acc[i] += b0[i] * w0 + b1[i] * w1;
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NACC; i++) {
+    double v = wave_sum(acc[i]);
+    if (lane == 0) red[wv][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (MODE == 0) {
+      if (threadIdx.x < 45) Hcc[45 * (int64_t)c + threadIdx.x] = v;
+      else out9[9 * (int64_t)c + threadIdx.x - 45] = v;
+    } else {
+      out9[9 * (int64_t)c + threadIdx.x] = v;
+    }
+  }
+}
+
+// ---- per point: U^-1 = (Hpp + lambda I)^-1 (6, symmetric) and u = U^-1 gp -------------------------------------
+__global__ __launch_bounds__(BLK) void k_schur_prep(int64_t npnts, double lambda, const double *__restrict__ Hpp,
+                                                     const double *__restrict__ gp, double *__restrict__ Uinv,
+                                                     double *__restrict__ u) {
+  int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= npnts) return;
+  const double *h = Hpp + 6 * p;
+  double a = h[0] + lambda, b = h[1], c = h[2], d = h[3] + lambda, e = h[4], f = h[5] + lambda;
+  // cofactors of the symmetric 3x3 [[a b c],[b d e],[c e f]]
+  double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  double c11 = a * f - c * c, c12 = b * c - a * e, c22 = a * d - b * b;
+  double det = a * c00 + b * c01 + c * c02;
+  double id = 1.0 / det;
+  double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = c11 * id, i12 = c12 * id, i22 = c22 * id;
+  double *o = Uinv + 6 * p;
+  o[0] = i00;
+  o[1] = i01;
+  o[2] = i02;
+  o[3] = i11;
+  o[4] = i12;
+  o[5] = i22;
+  const double *g = gp + 3 * p;
+  u[3 * p + 0] = i00 * g[0] + i01 * g[1] + i02 * g[2];
+  u[3 * p + 1] = i01 * g[0] + i11 * g[1] + i12 * g[2];
+  u[3 * p + 2] = i02 * g[0] + i12 * g[1] + i22 * g[2];
+}
+
+// ---- Schur blocks: one wave per (camera_a >= camera_b) key ---------------------------------------------------------
+// S[ca, cb] = [ca == cb] (Hcc[ca] + lambda I) - sum_tasks B_a' Q_ab B_b,   Q_ab = A_a U_p^-1 A_b'.
+// Per task the wave loads J_a (24), J_b (24) and U_p^-1 (6) with one coalesced instruction into its LDS slot,
+// lane l then owns elements l and 64+l (< 81) of the 9x9 block.  Only elements with global row >= col are written
+// (lower triangle, packed NB x NB tiles).
+__device__ inline void s_store(double *S, int64_t gr, int64_t gc, double v) {
+  int64_t ti = gr / NB, tj = gc / NB;
+  S[(tile_index(ti, tj) * NB + (gr - ti * NB)) * NB + (gc - tj * NB)] = v;
+}
+
+__global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *__restrict__ key_ptr,
+                                                       const int *__restrict__ key_ca, const int *__restrict__ key_cb,
+                                                       const int *__restrict__ task_a, const int *__restrict__ task_b,
+                                                       const int *__restrict__ pnt0, const double *__restrict__ J,
+                                                       const double *__restrict__ Uinv, const double *__restrict__ Hcc,
+                                                       double lambda, double *__restrict__ S) {
+  __shared__ double stage[BLK / 64][2][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t key = (int64_t)blockIdx.x * (BLK / 64) + wv;
+  if (key >= nkeys) return;
+  const int ca = key_ca[key], cb = key_cb[key];
+  const int e0 = lane, e1 = 64 + lane;
+  const int i0 = e0 / 9, j0 = e0 - 9 * i0;
+  const int i1 = (e1 < 81) ? e1 / 9 : 0, j1 = (e1 < 81) ? e1 - 9 * i1 : 0;
+  double acc0 = 0, acc1 = 0;
+  const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
+  int buf = 0;
+  for (int t = t_begin; t < t_end; t++, buf ^= 1) {
+    const int oa = task_a[t], ob = task_b[t];
+    double v = 0;
+    if (lane < 24) v = J[24 * (int64_t)oa + lane];
+    else if (lane < 48) v = J[24 * (int64_t)ob + lane - 24];
+    else if (lane < 54) v = Uinv[6 * (int64_t)pnt0[oa] + lane - 48];
+    double *sg = stage[wv][buf];
+    sg[lane] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double *Ja = sg, *Jb = sg + 24, *Ui = sg + 48;
+    // Y = U^-1 A_b'  (3x2), Q = A_a Y (2x2)
+    double y00 = Ui[0] * Jb[0] + Ui[1] * Jb[1] + Ui[2] * Jb[2];
+    double y10 = Ui[1] * Jb[0] + Ui[3] * Jb[1] + Ui[4] * Jb[2];
+    double y20 = Ui[2] * Jb[0] + Ui[4] * Jb[1] + Ui[5] * Jb[2];
+    double y01 = Ui[0] * Jb[12] + Ui[1] * Jb[13] + Ui[2] * Jb[14];
+    double y11 = Ui[1] * Jb[12] + Ui[3] * Jb[13] + Ui[4] * Jb[14];
+    double y21 = Ui[2] * Jb[12] + Ui[4] * Jb[13] + Ui[5] * Jb[14];
+    double q00 = Ja[0] * y00 + Ja[1] * y10 + Ja[2] * y20;
+    double q01 = Ja[0] * y01 + Ja[1] * y11 + Ja[2] * y21;
+    double q10 = Ja[12] * y00 + Ja[13] * y10 + Ja[14] * y20;
+    double q11 = Ja[12] * y01 + Ja[13] * y11 + Ja[14] * y21;
+    {
+      double ba0 = Ja[3 + i0], ba1 = Ja[15 + i0], bb0 = Jb[3 + j0], bb1 = Jb[15 + j0];
+      acc0 += (ba0 * q00 + ba1 * q10) * bb0 + (ba0 * q01 + ba1 * q11) * bb1;
+    }
+    {
+      double ba0 = Ja[3 + i1], ba1 = Ja[15 + i1], bb0 = Jb[3 + j1], bb1 = Jb[15 + j1];
+      acc1 += (ba0 * q00 + ba1 * q10) * bb0 + (ba0 * q01 + ba1 * q11) * bb1;
+    }
+  }
+  const int64_t r0 = 9 * (int64_t)ca, c0 = 9 * (int64_t)cb;
+  {
+    double v = -acc0;
+    if (ca == cb) {
+      int hi = i0 > j0 ? i0 : j0, lo = i0 > j0 ? j0 : i0;
+      v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i0 == j0 ? lambda : 0.0);
+    }
+    if (r0 + i0 >= c0 + j0) s_store(S, r0 + i0, c0 + j0, v);
+  }
+  if (e1 < 81) {
+    double v = -acc1;
+    if (ca == cb) {
+      int hi = i1 > j1 ? i1 : j1, lo = i1 > j1 ? j1 : i1;
+      v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i1 == j1 ? lambda : 0.0);
+    }
+    if (r0 + i1 >= c0 + j1) s_store(S, r0 + i1, c0 + j1, v);
+  }
+}
+
+// unit diagonal on the padding rows n..npad-1 so that the padded matrix stays factorisable
+__global__ void k_pad_diag(int64_t n, int64_t npad, double *S) {
+  int64_t i = n + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npad) s_store(S, i, i, 1.0);
+}
+
+// ---- back-substitution of the points: dp = -(u_p + U^-1 sum_a A_a' (B_a dc[c_a])) ----------------------------------
+__global__ __launch_bounds__(BLK) void k_backsub(int64_t npnts, const int *__restrict__ pt_ptr,
+                                                  const int *__restrict__ pt_obs, const int *__restrict__ cam0,
+                                                  const double *__restrict__ J, const double *__restrict__ Uinv,
+                                                  const double *__restrict__ u, const double *__restrict__ dc,
+                                                  double *__restrict__ dp) {
+  int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (p >= npnts) return;
+  double w[3] = {0, 0, 0};
+  for (int q = pt_ptr[p]; q < pt_ptr[p + 1]; q++) {
+    int64_t o = pt_obs[q];
+    const double *Jo = J + 24 * o;
+    const double *d = dc + 9 * (int64_t)cam0[o];
+    double s0 = 0, s1 = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      s0 += Jo[3 + i] * d[i];
+      s1 += Jo[15 + i] * d[i];
+    }
+    w[0] += Jo[0] * s0 + Jo[12] * s1;
+    w[1] += Jo[1] * s0 + Jo[13] * s1;
+    w[2] += Jo[2] * s0 + Jo[14] * s1;
+  }
+  const double *U = Uinv + 6 * p;
+  dp[3 * p + 0] = -(u[3 * p + 0] + (U[0] * w[0] + U[1] * w[1] + U[2] * w[2]));
+  dp[3 * p + 1] = -(u[3 * p + 1] + (U[1] * w[0] + U[3] * w[1] + U[4] * w[2]));
+  dp[3 * p + 2] = -(u[3 * p + 2] + (U[2] * w[0] + U[4] * w[1] + U[5] * w[2]));
+}
+
+// ---- model value: per-block partial sums of |J delta + r|^2 (delta in the layout of x) ------------------------------
+__global__ __launch_bounds__(BLK) void k_model_sq(int64_t nobs, int64_t npnts, const int *__restrict__ cam0,
+                                                   const int *__restrict__ pnt0, const double *__restrict__ J,
+                                                   const double *__restrict__ r, const double *__restrict__ delta,
+                                                   double *__restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  double acc = 0;
+  for (int64_t o = (int64_t)blockIdx.x * BLK + threadIdx.x; o < nobs; o += (int64_t)gridDim.x * BLK) {
+    const double *Jo = J + 24 * o;
+    const double *dp = delta + 3 * (int64_t)pnt0[o];
+    const double *dcm = delta + 3 * npnts + 9 * (int64_t)cam0[o];
+    double s0 = r[2 * o], s1 = r[2 * o + 1];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      s0 += Jo[i] * dp[i];
+      s1 += Jo[12 + i] * dp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      s0 += Jo[3 + i] * dcm[i];
+      s1 += Jo[15 + i] * dcm[i];
+    }
+    acc += s0 * s0 + s1 * s1;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// sum of squares of a vector -> per-block partials (fixed grid => fixed summation tree)
+__global__ __launch_bounds__(BLK) void k_sumsq(int64_t n, const double *__restrict__ v, double *__restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) acc += v[i] * v[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// final stage: one block sums `np` partials into out[slot]
+__global__ __launch_bounds__(BLK) void k_sum_partials(int np, const double *__restrict__ partial, double *__restrict__ out,
+                                                       int slot) {
+  __shared__ double red[BLK / 64];
+  double acc = 0;
+  for (int i = threadIdx.x; i < np; i += BLK) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[slot] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ __launch_bounds__(BLK) void k_axpy(int64_t n, const double *__restrict__ x, const double *__restrict__ d,
+                                               double *__restrict__ y) {
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) y[i] = x[i] + d[i];
+}
+
+__global__ __launch_bounds__(BLK) void k_scale_scalar(int64_t n, double *__restrict__ v, double alpha) {
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) v[i] *= alpha;
+}
+
+// column scaling of the normal equations (normalize = :J / :A, src/lma_aux.jl:102-154): s_j = sqrt(diag(J'J)_j [+ lambda])
+__global__ __launch_bounds__(BLK) void k_scale_vec(int64_t n, const double *__restrict__ s, double *__restrict__ v,
+                                                    int divide) {
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n && s[i] != 0) v[i] = divide ? v[i] / s[i] : v[i] * s[i];
+}
+
+}  // namespace
+
+static inline unsigned grid_for(int64_t n, int blk) { return (unsigned)((n + blk - 1) / blk); }
+
+int launch_point_blocks(ba_problem *p, const double *d_J, const double *d_r, double *d_Hpp, double *d_gp,
+                        hipStream_t st) {
+  if (p->npnts == 0) return BA_OK;
+  ProfScope ps(p, PC_POINT_BLOCKS, st);
+  hipLaunchKernelGGL(k_point_blocks, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->pt_obs,
+                     d_J, d_r, d_Hpp, d_gp);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, double *d_Hcc, double *d_gc,
+                      hipStream_t st) {
+  if (p->ncams == 0) return BA_OK;
+  ProfScope ps(p, PC_CAM_BLOCKS, st);
+  if (d_Hcc)
+    hipLaunchKernelGGL(k_cam_blocks<0>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
+                       d_r, (const double *)nullptr, d_Hcc, d_gc);
+  else
+    hipLaunchKernelGGL(k_cam_blocks<1>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
+                       d_r, (const double *)nullptr, (double *)nullptr, d_gc);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const double *d_gp, double *d_Uinv,
+                      double *d_u, hipStream_t st) {
+  if (p->npnts == 0) return BA_OK;
+  ProfScope ps(p, PC_SCHUR_PREP, st);
+  hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, lambda, d_Hpp, d_gp,
+                     d_Uinv, d_u);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv,
+                        const double *d_Hcc, double lambda, double *d_S, int64_t n, int64_t npad, hipStream_t st) {
+  ProfScope ps(p, PC_SCHUR_S, st);
+  BA_HIP_CHECK(hipMemsetAsync(d_S, 0, (size_t)dense_ldl_tiles_doubles(n) * sizeof(double), st));
+  if (T->nkeys > 0)
+    hipLaunchKernelGGL(k_schur_blocks, dim3(grid_for(T->nkeys, BLK / 64)), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
+                       T->key_ca, T->key_cb, T->task_a, T->task_b, p->pnt0, d_J, d_Uinv, d_Hcc, lambda, d_S);
+  if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
+                     hipStream_t st) {
+  if (p->ncams == 0) return BA_OK;
+  ProfScope ps(p, PC_SCHUR_RHS, st);
+  hipLaunchKernelGGL(k_cam_blocks<2>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
+                     d_r, d_u, (double *)nullptr, d_rhs);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,
+                   double *d_dp, hipStream_t st) {
+  if (p->npnts == 0) return BA_OK;
+  ProfScope ps(p, PC_BACKSUB, st);
+  hipLaunchKernelGGL(k_backsub, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->pt_obs, p->cam0,
+                     d_J, d_Uinv, d_u, d_dc, d_dp);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+// |J delta + r|^2 -> scal[slot]
+int launch_model_sq(ba_problem *p, const double *d_J, const double *d_r, const double *d_delta, double *d_partial,
+                    double *d_scal, int slot, hipStream_t st) {
+  ProfScope ps(p, PC_TRIAL, st);
+  int nb = (int)((p->nobs + BLK - 1) / BLK);
+  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_model_sq, dim3(nb), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_J, d_r, d_delta,
+                     d_partial);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLK), 0, st, nb, d_partial, d_scal, slot);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+// |v|^2 -> scal[slot]
+int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial, double *d_scal, int slot,
+                 hipStream_t st) {
+  ProfScope ps(p, PC_REDUCE, st);
+  int nb = (int)((n + BLK - 1) / BLK);
+  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(BLK), 0, st, n, d_v, d_partial);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLK), 0, st, nb, d_partial, d_scal, slot);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st) {
+  if (n == 0) return BA_OK;
+  hipLaunchKernelGGL(k_axpy, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, d_x, d_d, d_y);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_scale_scalar(ba_problem *p, int64_t n, double *d_v, double alpha, hipStream_t st) {
+  if (n == 0) return BA_OK;
+  hipLaunchKernelGGL(k_scale_scalar, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, d_v, alpha);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_scale_vec(ba_problem *p, int64_t n, const double *d_s, double *d_v, int divide, hipStream_t st) {
+  if (n == 0) return BA_OK;
+  hipLaunchKernelGGL(k_scale_vec, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, d_s, d_v, divide);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}

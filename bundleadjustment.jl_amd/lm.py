@@ -1,0 +1,119 @@
+"""Levenberg_Marquardt(model, facto, perm, normalize[, linesearch]; kwargs...) -- host mirror of the two solver
+entry points of the reference over ba_lm_solve (include/ba_hip.h):
+
+  * 4 positional arguments  -> src/LevenbergMarquardt.jl:16-26 (old API; what src/solve_ba.jl:26 calls)
+  * 5 positional arguments  -> src/lm.jl:15-26 (new API with `linesearch`; src/main.jl:30, src/diffprecsions.jl:41)
+
+Keyword names follow the reference with ASCII spellings (νd -> nu_d, νm -> nu_m, λ -> lam, δd -> delta_d).
+Returns a GenericExecutionStats with the fields the reference fills (src/lm.jl:409-415,
+src/LevenbergMarquardt.jl:384).
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .model import BALNLPModel, FeasibilityResidual
+
+_FACTO = {"LDL": 0, "QR": 1}
+_NORM = {"None": 0, "J": 1, "A": 2}
+_PERM = ("AMD", "Metis")
+
+
+@dataclass
+class GenericExecutionStats:
+    status: str
+    solution: np.ndarray
+    objective: float
+    iter: int
+    elapsed_time: float
+    dual_feas: float = float("inf")
+    primal_feas: float = float("inf")
+    # extras (not in the reference struct)
+    loop_time: float = 0.0
+    n_accepted: int = 0
+    n_rejected: int = 0
+    n_residual: int = 0
+    n_jacobian: int = 0
+    n_factor: int = 0
+    lambda_final: float = 0.0
+    log: list = field(default_factory=list)
+
+    def __str__(self):
+        return (f"Generic Execution stats\n  status: {self.status}\n  objective value: {self.objective!r}\n"
+                f"  primal feasibility: {self.primal_feas!r}\n  dual feasibility: {self.dual_feas!r}\n"
+                f"  solution: [{'  '.join(repr(float(v)) for v in self.solution[:4])} ⋯ {float(self.solution[-1])!r}]\n"
+                f"  iterations: {self.iter}\n  elapsed time: {self.elapsed_time!r}")
+
+
+def _sym(s):
+    return s[1:] if isinstance(s, str) and s.startswith(":") else s
+
+
+def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=None, facto_type=None,
+                        restol=None, satol=None, srtol=None, oatol=None, ortol=None, atol=None, rtol=None,
+                        nu_d=None, nu_m=None, lam=None, delta_d=None, ite_max=None, max_time=None, verbose=False,
+                        log=True):
+    facto, perm, normalize = _sym(facto), _sym(perm), _sym(normalize)
+    if facto not in _FACTO:
+        raise ValueError(f"facto must be :QR or :LDL, got {facto!r}")
+    if perm not in _PERM:
+        raise ValueError(f"perm must be :AMD or :Metis, got {perm!r}")
+    if normalize not in _NORM:
+        raise ValueError(f"normalize must be :None, :J or :A, got {normalize!r}")
+    nlp = model.nlp if isinstance(model, FeasibilityResidual) else model
+    if not isinstance(nlp, BALNLPModel):
+        raise TypeError("model must be a FeasibilityResidual(BALNLPModel) or a BALNLPModel")
+    if nlp.T is not np.float64:
+        raise NotImplementedError("the device LM iterates in Float64 (eltype(x) = Float32 runs are not implemented)")
+    variant = 0 if linesearch is None else 1
+    if variant == 0 and (facto_type is not None or max_time is not None):
+        raise TypeError("LevenbergMarquardt.jl's Levenberg_Marquardt has no facto_type / max_time keyword")
+    x0 = np.array(nlp.meta.x0 if x is None else x, dtype=np.float64, copy=True)
+    if x0.shape != (nlp.meta.nvar,):
+        raise ValueError("x has the wrong length")
+    f32 = facto_type is not None and np.dtype(facto_type) == np.float32
+    if facto_type is not None and np.dtype(facto_type) not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise NotImplementedError("facto_type must be Float64 or Float32 (the Float16 path of lm.jl:165-169 is experimental "
+                                  "in the reference and not provided)")
+
+    def d(v):
+        return -1.0 if v is None else float(v)
+
+    o = _lib.LMOpts(variant=variant, facto=_FACTO[facto], normalize=_NORM[normalize], linesearch=int(bool(linesearch)),
+                    facto_f32=int(f32), ite_max=-1 if ite_max is None else int(ite_max), verbose=int(verbose), reserved0=0,
+                    restol=d(restol), satol=d(satol), srtol=d(srtol), oatol=d(oatol), ortol=d(ortol), atol=d(atol),
+                    rtol=d(rtol), nu_d=d(nu_d), nu_m=d(nu_m), lam=d(lam), delta_d=d(delta_d), max_time=d(max_time))
+    st = _lib.LMStats()
+    rows = []
+
+    def _cb(ctx, it, f, df, njtr, lmb, nd, rho, acc):
+        rows.append((it, f, df, njtr, lmb, nd, rho, bool(acc)))
+
+    cb = _lib.LOG_CB(_cb) if log else C.cast(None, _lib.LOG_CB)
+    _lib.check(_lib.lib().ba_lm_solve(nlp.handle, C.byref(o), _lib.ptr(x0), C.byref(st), cb, None))
+    nlp.counters.neval_cons += st.n_residual
+    nlp.counters.neval_residual += st.n_residual
+    nlp.counters.neval_jac += st.n_jacobian + 1  # + jac_structure! (src/BALNLPModels.jl:126)
+    nlp.counters.neval_jac_residual += st.n_jacobian
+    out = GenericExecutionStats(status=_lib.STATUS[st.status], solution=x0, objective=st.objective, iter=st.iter,
+                                elapsed_time=st.elapsed_s, loop_time=st.loop_s, n_accepted=st.n_accepted,
+                                n_rejected=st.n_rejected, n_residual=st.n_residual, n_jacobian=st.n_jacobian,
+                                n_factor=st.n_factor, lambda_final=st.lambda_final, log=rows)
+    if variant == 1:
+        out.dual_feas = st.dual_feas    # lm.jl:415
+    else:
+        out.primal_feas = st.dual_feas  # LevenbergMarquardt.jl:384 passes |J'r| as primal_feas
+    return out
+
+
+def lm_step(nlp, x, lam, want_jtr=True):
+    """One linear LM step from (x, lambda): delta, 1/2|J delta + r|^2, J'r  (ba_lm_step)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    delta = np.empty(nlp.meta.nvar)
+    jtr = np.empty(nlp.meta.nvar) if want_jtr else None
+    half = C.c_double(0)
+    _lib.check(_lib.lib().ba_lm_step(nlp.handle, _lib.ptr(x), float(lam), _lib.ptr(delta), C.byref(half),
+                                     _lib.ptr(jtr) if want_jtr else None))
+    return delta, half.value, jtr

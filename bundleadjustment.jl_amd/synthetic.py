@@ -1,0 +1,147 @@
+"""Seeded synthetic BAL-shaped problems (no BAL file is available offline) and a BAL writer.
+
+Generator spec: unit-ball points; rotation vectors axis*angle with angle ~ U(0.05, 1.5)
+(never 0: theta = 0 is NaN in the reference, src/BALNLPModels.jl:19-23); camera centres at distance 6 +- 1 looking at
+the origin down -z so that P1.z is in (-8, -4) (never 0, :26-31); f ~ U(400, 1800); k1 ~ -U(0,5)e-7; k2 ~ U(0,1)e-12
+(magnitudes of the fixture of test/runtests.jl:18); per-point degree >= 2 from a shifted geometric law adjusted so
+that the degrees sum to nobs exactly; cameras of a point distinct and uniformly drawn (=> the reduced camera matrix
+is dense); observations sorted by point then camera (BAL order, test/runtests.jl:16-17);
+pt2d = projection(x_true) + N(0, 0.5^2) px; x0 = x_true with points + N(0, 0.02^2), cameras * (1 + N(0, 1e-3^2)).
+"""
+import bz2
+import os
+
+import numpy as np
+
+# (ncams, npnts, nobs) of the configurations of BASELINE.json
+SHAPES = {
+    "ladybug-49": (49, 7776, 31843),
+    "dubrovnik-356": (356, 226730, 1255268),
+    "venice-1778": (1778, 993923, 5001946),
+    "final-13682": (13682, 4456117, 28987644),
+}
+BASE_SEED = 20261004
+
+
+def project(points, cams):
+    """Vectorised BAL projection of points (n,3) by cameras (n,9) in the reference's camera layout
+    (r, t, k1, k2, f).  Data generation only; parity checks use oracle/."""
+    r, t = cams[:, :3], cams[:, 3:6]
+    k1, k2, f = cams[:, 6], cams[:, 7], cams[:, 8]
+    th = np.sqrt((r * r).sum(1))[:, None]
+    k = r / th
+    c, s = np.cos(th), np.sin(th)
+    d = (k * points).sum(1)[:, None]
+    P1 = c * points + s * np.cross(k, points) + (1 - c) * d * k + t
+    P2 = -P1[:, :2] / P1[:, 2:3]
+    n = (P2 * P2).sum(1)
+    return (f * (1.0 + k1 * n + k2 * n * n))[:, None] * P2
+
+
+def _degrees(rng, npnts, nobs, ncams):
+    lo, hi = 2, ncams
+    if nobs < lo * npnts or nobs > hi * npnts:
+        raise ValueError("nobs must lie in [2*npnts, ncams*npnts]")
+    mean_extra = nobs / npnts - lo
+    if mean_extra <= 0:
+        deg = np.full(npnts, lo, dtype=np.int64)
+    else:
+        pgeo = 1.0 / (1.0 + mean_extra)
+        deg = lo + rng.geometric(pgeo, size=npnts).astype(np.int64) - 1
+        deg = np.minimum(deg, hi)
+    diff = int(nobs - deg.sum())
+    while diff != 0:
+        step = 1 if diff > 0 else -1
+        cand = np.flatnonzero(deg < hi) if step > 0 else np.flatnonzero(deg > lo)
+        take = min(abs(diff), len(cand))
+        pick = rng.choice(cand, size=take, replace=False)
+        deg[pick] += step
+        diff -= step * take
+    return deg
+
+
+def make_problem(ncams, npnts, nobs, seed=BASE_SEED):
+    """-> dict(cam_idx1, pnt_idx1, pt2d, x0, x_true, ncams, npnts, nobs) in the reference's conventions."""
+    rng = np.random.default_rng(seed)
+    # points in the unit ball
+    g = rng.standard_normal((npnts, 3))
+    g /= np.linalg.norm(g, axis=1)[:, None]
+    pts = g * rng.random((npnts, 1)) ** (1.0 / 3.0)
+    # cameras
+    axis = rng.standard_normal((ncams, 3))
+    axis /= np.linalg.norm(axis, axis=1)[:, None]
+    ang = rng.uniform(0.05, 1.5, size=(ncams, 1))
+    rvec = axis * ang
+    rho = rng.uniform(5.0, 7.0, size=ncams)
+    tvec = np.zeros((ncams, 3))
+    tvec[:, 2] = -rho  # P1 = R X - rho e_z  => P1.z in (-8, -4)
+    f = rng.uniform(400.0, 1800.0, size=ncams)
+    k1 = -rng.uniform(0.0, 5.0, size=ncams) * 1e-7
+    k2 = rng.uniform(0.0, 1.0, size=ncams) * 1e-12
+    cams = np.column_stack([rvec, tvec, k1, k2, f])
+    # observation graph
+    deg = _degrees(rng, npnts, nobs, ncams)
+    pnt0 = np.repeat(np.arange(npnts, dtype=np.int64), deg)
+    cam0 = rng.integers(0, ncams, size=nobs, dtype=np.int64)
+    for _ in range(200):
+        order = np.lexsort((cam0, pnt0))
+        cam0 = cam0[order]
+        dup = np.flatnonzero((pnt0[1:] == pnt0[:-1]) & (cam0[1:] == cam0[:-1])) + 1
+        if dup.size == 0:
+            break
+        cam0[dup] = rng.integers(0, ncams, size=dup.size, dtype=np.int64)
+    else:
+        raise RuntimeError("could not draw distinct cameras per point")
+    proj = project(pts[pnt0], cams[cam0])
+    pt2d = (proj + rng.normal(0.0, 0.5, size=proj.shape)).ravel()
+    x_true = np.concatenate([pts.ravel(), cams.ravel()])
+    pts0 = pts + rng.normal(0.0, 0.02, size=pts.shape)
+    cams0 = cams * (1.0 + rng.normal(0.0, 1e-3, size=cams.shape))
+    x0 = np.concatenate([pts0.ravel(), cams0.ravel()])
+    return dict(cam_idx1=cam0 + 1, pnt_idx1=pnt0 + 1, pt2d=np.ascontiguousarray(pt2d), x0=x0, x_true=x_true,
+                ncams=int(ncams), npnts=int(npnts), nobs=int(nobs))
+
+
+def make_named(name, seed_offset=0, scale=1.0):
+    """One of SHAPES, optionally shrunk by `scale` (observations per point kept)."""
+    ncams, npnts, nobs = SHAPES[name]
+    if scale != 1.0:
+        ncams = max(4, int(round(ncams * scale)))
+        npnts2 = max(8, int(round(npnts * scale)))
+        nobs = max(2 * npnts2, int(round(nobs * npnts2 / npnts)))
+        nobs = min(nobs, ncams * npnts2)
+        npnts = npnts2
+    return make_problem(ncams, npnts, nobs, BASE_SEED + seed_offset)
+
+
+def as_arrays(prob, T=np.float64):
+    """tuple in the order readfile() returns (src/ReadFiles.jl:52)."""
+    return (prob["cam_idx1"], prob["pnt_idx1"], prob["pt2d"].astype(T), prob["x0"].astype(T), prob["ncams"],
+            prob["npnts"], prob["nobs"])
+
+
+def write_bal(path, prob, x=None):
+    """Write a problem in BAL text format (bzip2 when the name ends in .bz2): 0-based indices, camera order
+    r t f k1 k2 (the reader restores r t k1 k2 f, src/ReadFiles.jl:32-43).  %.17g round-trips Float64."""
+    x = prob["x0"] if x is None else x
+    ncams, npnts, nobs = prob["ncams"], prob["npnts"], prob["nobs"]
+    pts = x[: 3 * npnts]
+    cams = x[3 * npnts:].reshape(ncams, 9)
+    lines = [f"{ncams} {npnts} {nobs}"]
+    p2 = prob["pt2d"].reshape(nobs, 2)
+    for k in range(nobs):
+        lines.append(f"{prob['cam_idx1'][k] - 1} {prob['pnt_idx1'][k] - 1}     {p2[k, 0]:.17g} {p2[k, 1]:.17g}")
+    for c in cams:
+        for v in (c[0], c[1], c[2], c[3], c[4], c[5], c[8], c[6], c[7]):
+            lines.append(f"{v:.17g}")
+    for v in pts:
+        lines.append(f"{v:.17g}")
+    data = ("\n".join(lines) + "\n").encode()
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    if path.endswith(".bz2"):
+        with bz2.open(path, "wb") as fh:
+            fh.write(data)
+    else:
+        with open(path, "wb") as fh:
+            fh.write(data)
+    return path

@@ -1,0 +1,184 @@
+/*
+ * ba_hip.h -- C ABI of libba_hip.so, the MI355X (gfx950) implementation of the hot path of
+ * CelestineAngla/BundleAdjustment.jl.  Plain C types only; every entry returns an int status
+ * (BA_OK == 0) and never throws.  ba_last_error() returns the text of the last failure of the
+ * calling thread.
+ *
+ * Each entry names the reference interface it replaces (paths relative to the reference root).
+ * Conventions are the reference's own at this boundary:
+ *   - indices are 1-based int64 (Julia Int);
+ *   - the unknown vector is x = [X_1(3) ... X_npnts(3) ; C_1(9) ... C_ncams(9)], camera
+ *     C = (r1,r2,r3,t1,t2,t3,k1,k2,f)                      (src/ReadFiles.jl:29-40);
+ *   - pt2d and residuals are interleaved (x,y) per observation;
+ *   - Jacobian COO entries: 24 per observation, row-major 2x12 block, column order
+ *     [X(3), r(3), t(3), k1, k2, f]                        (src/BALNLPModels.jl:137-153,201).
+ * Host-pointer entries copy in/out and keep no caller pointer after returning (the Julia GC may
+ * move or free the arrays).  *_dev entries take device pointers (hipMalloc'ed by the caller, e.g.
+ * a torch tensor's data_ptr, or by ba_dev_malloc) and enqueue on the given hipStream_t
+ * (void* 0 = the handle's own stream) without synchronising.
+ */
+#ifndef BA_HIP_H
+#define BA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  BA_OK = 0,
+  BA_ERR_ARG = 1,       /* bad argument (null pointer, index out of range, size mismatch) */
+  BA_ERR_HIP = 2,       /* HIP runtime error (no device, out of memory, launch failure) */
+  BA_ERR_IO = 3,        /* BAL file missing / malformed / bzip2 runtime missing */
+  BA_ERR_ZERO_PIVOT = 4,/* LDL^T met an exactly zero pivot: SQDException, src/ldl_aux.jl:45-47,199 */
+  BA_ERR_NAN_STEP = 5,  /* |delta| is NaN: status :exception, src/lm.jl:297-302 */
+  BA_ERR_COMM = 6       /* the caller's all-reduce hook failed */
+};
+
+/* status of a Levenberg-Marquardt run: src/lm.jl:391-405, src/LevenbergMarquardt.jl:370-380 */
+enum {
+  BA_ST_UNKNOWN = -1,
+  BA_ST_SMALL_STEP = 0,
+  BA_ST_FIRST_ORDER = 1,
+  BA_ST_SMALL_RESIDUAL = 2,
+  BA_ST_ACCEPTABLE = 3,
+  BA_ST_NEG_PRED = 4,
+  BA_ST_EXCEPTION = 5,
+  BA_ST_MAX_ITER = 6
+};
+
+typedef struct ba_problem ba_problem; /* opaque: device mirrors of one BALNLPModel (src/BALNLPModels.jl:79-88) */
+
+const char *ba_last_error(void);
+int ba_device_count(int *n);
+/* name/CU count of device `dev` (for logs) */
+int ba_device_info(int dev, char *name, size_t name_cap, int *n_cu, size_t *hbm_bytes);
+
+/* ---- BAL reader: readfile(filename, T)  src/ReadFiles.jl:9-53 ------------------------------
+ * `path` is a full path to problem-*.txt or problem-*.txt.bz2 (the reference prepends
+ * <repo>/Data/, ReadFiles.jl:10; the host shim does that).  Two calls: header, then body into
+ * caller-allocated arrays of the sizes the header gave.  Indices come back 1-based, cameras
+ * re-ordered from the file's (r,t,f,k1,k2) to (r,t,k1,k2,f) exactly as ReadFiles.jl:32-43.
+ * The _f32 twin parses every decimal straight to float (parse(Float32, .), single rounding). */
+int ba_read_bal_header(const char *path, int64_t *ncams, int64_t *npnts, int64_t *nobs);
+int ba_read_bal(const char *path, int64_t ncams, int64_t npnts, int64_t nobs, int64_t *cam_idx1,
+                int64_t *pnt_idx1, double *pt2d, double *x0);
+int ba_read_bal_f32(const char *path, int64_t ncams, int64_t npnts, int64_t nobs, int64_t *cam_idx1,
+                    int64_t *pnt_idx1, float *pt2d, float *x0);
+
+/* ---- model: BALNLPModel(...)  src/BALNLPModels.jl:91-106 ------------------------------------
+ * Copies the index arrays and pt2d to device `device` (int32 0-based mirrors + the point- and
+ * camera-sorted observation lists used by the deterministic reductions).  In a multi-GPU run every
+ * rank creates its own shard: local observations, local points renumbered 1..npnts_local, ALL
+ * cameras (cam_idx1 stays global). */
+int ba_problem_create(int device, int64_t ncams, int64_t npnts, int64_t nobs, const int64_t *cam_idx1,
+                      const int64_t *pnt_idx1, const double *pt2d, ba_problem **out);
+void ba_problem_destroy(ba_problem *p);
+int ba_problem_dims(const ba_problem *p, int64_t *ncams, int64_t *npnts, int64_t *nobs, int64_t *nvar,
+                    int64_t *nequ, int64_t *nnzj);
+
+/* cons!(nlp, x, cx) == residual!(FeasibilityResidual(nlp), x, r)  src/BALNLPModels.jl:115-122,39-55 */
+int ba_residual(ba_problem *p, const double *x, double *r);
+int ba_residual_f32(ba_problem *p, const float *x, float *r); /* BALNLPModel(file, Float32) */
+/* jac_structure!(nlp, rows, cols)  src/BALNLPModels.jl:125-158 : 24*nobs 1-based int64 each */
+int ba_jac_structure(ba_problem *p, int64_t *rows, int64_t *cols);
+/* jac_coord!(nlp, x, vals)  src/BALNLPModels.jl:161-206 + src/JacobianByHand.jl:5-101, NaN -> 0 */
+int ba_jac_coord(ba_problem *p, const double *x, double *vals);
+int ba_jac_coord_f32(ba_problem *p, const float *x, float *vals);
+/* J' r from COO values: mul_sparse(cols, rows, vals, r, nnzj, nvar)  src/lma_aux.jl:194-212 as
+ * called at src/lm.jl:57,370.  jtr has nvar entries in the layout of x. */
+int ba_jtr(ba_problem *p, const double *vals, const double *r, double *jtr);
+
+/* device-resident twins (no host copies, no synchronisation): what bench.py times */
+int ba_residual_dev(ba_problem *p, const double *d_x, double *d_r, void *stream);
+int ba_residual_f32_dev(ba_problem *p, const float *d_x, float *d_r, void *stream);
+int ba_jac_structure_dev(ba_problem *p, int64_t *d_rows, int64_t *d_cols, void *stream);
+int ba_jac_coord_dev(ba_problem *p, const double *d_x, double *d_vals, void *stream);
+int ba_jac_coord_f32_dev(ba_problem *p, const float *d_x, float *d_vals, void *stream);
+int ba_jtr_dev(ba_problem *p, const double *d_vals, const double *d_r, double *d_jtr, void *stream);
+
+/* small device-memory helpers so that a C / Julia caller needs no HIP binding of its own */
+int ba_dev_malloc(ba_problem *p, size_t bytes, void **d_ptr);
+int ba_dev_free(ba_problem *p, void *d_ptr);
+int ba_memcpy_h2d(ba_problem *p, void *d_dst, const void *h_src, size_t bytes);
+int ba_memcpy_d2h(ba_problem *p, void *h_dst, const void *d_src, size_t bytes);
+int ba_synchronize(ba_problem *p);
+
+/* ---- Levenberg_Marquardt(model, facto, perm, normalize[, linesearch]; kwargs...) --------------
+ * variant 0: src/LevenbergMarquardt.jl:16-385 (what solve_ba.jl runs); variant 1: src/lm.jl:15-418.
+ * The linear step (J'J + lambda I) delta = -J' r -- which the reference obtains from a sparse LDL^T
+ * (or QR) of the augmented system, src/lm.jl:154-238 -- is solved on the device through the
+ * point-eliminated (Schur) reduced camera system and a dense blocked LDL^T on the f64 matrix cores;
+ * `facto` and `perm` therefore only select behaviour that survives that change (both :QR and :LDL
+ * give the same step; the fill-reducing ordering has no counterpart).  Negative tolerances / zero
+ * parameters mean "the variant's default" (eps-derived, src/lm.jl:20-26 and
+ * src/LevenbergMarquardt.jl:21-26). */
+typedef struct ba_lm_opts {
+  int variant;    /* 0 LevenbergMarquardt.jl, 1 lm.jl */
+  int facto;      /* 0 :LDL, 1 :QR (same device solve) */
+  int normalize;  /* 0 :None, 1 :J, 2 :A  (src/lma_aux.jl:102-178) */
+  int linesearch; /* lm.jl only, src/lm.jl:264-295 */
+  int facto_f32;  /* lm.jl only: facto_type = Float32 (src/lm.jl:170-173, src/diffprecsions.jl:39-41) */
+  int ite_max;    /* <0: default (200 / 100) */
+  int verbose;    /* 1: print the reference's log columns to stderr */
+  int reserved0;
+  double restol, satol, srtol, oatol, ortol, atol, rtol; /* <0: default */
+  double nu_d, nu_m, lambda, delta_d;                    /* <=0: default (3, 3, 30 | 0.1, 2) */
+  double max_time;                                        /* <=0: 3600 (inert in the reference, lm.jl:33,115,382) */
+} ba_lm_opts;
+
+typedef struct ba_lm_stats {
+  int status;  /* BA_ST_* */
+  int iter;    /* LM iterations (lm.jl:127 / LevenbergMarquardt.jl:240) */
+  int n_accepted, n_rejected;
+  int n_residual, n_jacobian, n_factor;
+  int reserved0;
+  double objective;    /* 1/2 |r|^2 at the returned x */
+  double dual_feas;    /* |J' r| (lm.jl:415; primal_feas in the old variant, LevenbergMarquardt.jl:384) */
+  double lambda_final;
+  double elapsed_s;    /* whole call, host wall clock */
+  double loop_s;       /* the while-loop only (what iter / time is quoted on) */
+} ba_lm_stats;
+
+/* one log row per iteration, the reference's columns (src/lm.jl:120-121,304):
+ * iter, f, delta_f, |J'r|, lambda, |delta|, rho = ared/pred (variant 0: 1/2|dr|^2), accepted(1/0) */
+typedef void (*ba_log_cb)(void *ctx, int iter, double f, double df, double norm_jtr, double lambda,
+                          double norm_delta, double rho, int accepted);
+
+/* x_inout: nvar doubles, x0 in, solution out (the `x=` keyword of src/lm.jl:20). */
+int ba_lm_solve(ba_problem *p, const ba_lm_opts *opts, double *x_inout, ba_lm_stats *stats, ba_log_cb cb,
+                void *cb_ctx);
+
+/* ---- multi-GPU: observations sharded by point, cameras replicated --------------------------------
+ * The only cross-rank data of an iteration are camera-side sums.  The library keeps them in ONE
+ * caller-provided device buffer (so the caller's communication library owns the memory) and calls
+ * the hook to sum a sub-range of it over all ranks in place, on `stream`.  With no hook the run is
+ * single-GPU.  ba_lm_reduce_doubles() gives the buffer length for this shard's camera count. */
+typedef int (*ba_allreduce_fn)(void *ctx, int64_t offset_doubles, int64_t count_doubles, void *stream);
+int ba_lm_reduce_doubles(ba_problem *p, int64_t *count);
+int ba_lm_set_comm(ba_problem *p, int rank, int world, double *d_reduce_buf, int64_t buf_doubles,
+                   ba_allreduce_fn fn, void *ctx);
+
+/* ---- single linear step, exposed for parity tests and profiling ------------------------------------
+ * From (x, lambda): delta (nvar) solving (J'J + lambda I) delta = -J' r, and pred2 = 1/2 |J delta + r|^2
+ * (== 1/2 |delta_r|^2 of the reference's augmented solve, src/lm.jl:229). */
+int ba_lm_step(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
+               double *jtr /* nvar or NULL */);
+
+/* ---- per-kernel timing (hipEvent pairs on the handle's stream) ------------------------------------ */
+int ba_profile_enable(ba_problem *p, int on);
+int ba_profile_reset(ba_problem *p);
+/* fills up to cap entries; returns the number of kernel classes in *n.  names[i] points into static storage. */
+int ba_profile_get(ba_problem *p, int cap, const char **names, double *total_ms, int64_t *calls, int *n);
+
+/* dense blocked LDL^T on the f64 matrix cores, exposed for tests / roofline measurement:
+ * factor the symmetric n x n matrix whose lower triangle is given row-major (ld = n) in host memory and
+ * solve A x = b.  status BA_ERR_ZERO_PIVOT on an exactly zero pivot. */
+int ba_dense_ldl_solve(int device, int64_t n, const double *a_lower_rowmajor, const double *b, double *x,
+                       double *factor_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BA_HIP_H */

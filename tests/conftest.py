@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ba():
+    return ge.load_package()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    o = ge.load_oracle()
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def fixture_runtests():
+    return np.load(os.path.join(GOLDEN, "runtests_fixture.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_scipy():
+    return np.load(os.path.join(GOLDEN, "residual_scipy.npz"))
+
+
+@pytest.fixture(scope="session")
+def small_prob(ba):
+    return ba.synthetic.make_problem(12, 400, 1800, seed=11)
+
+
+@pytest.fixture(scope="session")
+def gpu_ok(ba):
+    if ba.device_count() < 1:
+        pytest.fail("this test needs the HIP device: there is no CPU fallback in the product path")
+    return True

@@ -1,0 +1,268 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Needs an MI355X: run with -m gpu.
+Tolerances (stated, fp64):
+  * Jacobian pattern: bit-exact int64.
+  * residuals: |r_gpu - r_oracle| <= 32 ulp of max(|proj|, 1)  (device sin/cos/sqrt/div differ from libm in the last
+    bits; the reference's own fixture, test/runtests.jl:27, is therefore matched to that bound, not to 0).
+  * Jacobian values: <= 1e-12 relative to the inf-norm of the 2x12 block.
+  * J'r: <= 1e-12 relative to max|J'r| (different, but fixed, summation order).
+  * one LM step from identical (x, lambda): |delta - delta_ref| / |delta_ref| <= 1e-9 for lambda >= 1e-2 on the
+    synthetic shapes; 1/2|J delta + r|^2 to 1e-9 relative.
+  * LM run: identical accept/reject sequence and iteration count on the small shapes, final objective <= 1e-8 relative.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+EPS = 2.220446049250313e-16
+
+
+@pytest.fixture(scope="module")
+def nlp_small(ba, small_prob, gpu_ok):
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(small_prob), model_name="small")
+    yield m
+    m.close()
+
+
+def _res_tol(r_ref, pt2d):
+    return 32 * EPS * np.maximum(np.abs(r_ref + pt2d), 1.0)
+
+
+def test_library_is_the_hip_one(ba, gpu_ok):
+    import ctypes
+    assert ba._lib.lib()._name.endswith("libba_hip.so")
+    n = ctypes.c_int(0)
+    assert ba._lib.lib().ba_device_count(ctypes.byref(n)) == 0 and n.value >= 1
+
+
+def test_runtests_fixture_through_c_abi(ba, fixture_runtests, gpu_ok):
+    f = fixture_runtests
+    m = ba.BALNLPModel(arrays=(f["cam_idx"], f["pnt_idx"], f["pt2d"], f["x"], 5, 1, 5))
+    r = m.cons(f["x"])
+    assert np.all(np.abs(r - f["true_residuals"]) <= _res_tol(f["true_residuals"], f["pt2d"]))
+    m.close()
+
+
+def test_residual_matches_reference_python_golden(ba, golden_scipy, gpu_ok):
+    g = golden_scipy
+    m = ba.BALNLPModel(arrays=(g["cam_idx1"], g["pnt_idx1"], g["pt2d"], g["x0"], int(g["ncams"]), int(g["npnts"]),
+                               len(g["cam_idx1"])))
+    for tag, x in (("x0", g["x0"]), ("xtrue", g["x_true"])):
+        r = m.cons(x)
+        assert np.all(np.abs(r - g["res_" + tag]) <= _res_tol(g["res_" + tag], g["pt2d"]))
+    m.close()
+
+
+def test_residual_vs_oracle(ba, orc, small_prob, nlp_small):
+    p = small_prob
+    r = nlp_small.cons(p["x0"])
+    r_ref = orc.residuals(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["pt2d"], p["npnts"])
+    err = np.abs(r - r_ref) / np.maximum(np.abs(r_ref + p["pt2d"]), 1.0) / EPS
+    print("residual max err [ulp of proj]:", err.max())
+    assert err.max() <= 32
+
+
+def test_jac_structure_bit_exact(ba, orc, small_prob, nlp_small):
+    p = small_prob
+    rows, cols = nlp_small.jac_structure()
+    rr, cc = orc.jac_structure(p["cam_idx1"], p["pnt_idx1"], p["npnts"])
+    assert rows.dtype == np.int64 and np.array_equal(rows, rr) and np.array_equal(cols, cc)
+
+
+def test_jac_coord_vs_oracle(ba, orc, small_prob, nlp_small):
+    p = small_prob
+    v = nlp_small.jac_coord(p["x0"]).reshape(-1, 24)
+    v_ref = orc.jac_coord(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["npnts"]).reshape(-1, 24)
+    rel = np.abs(v - v_ref).max(1) / np.abs(v_ref).max(1)
+    print("jacobian max block-relative err:", rel.max())
+    assert rel.max() <= 1e-12
+
+
+def test_jtr_vs_oracle(ba, orc, small_prob, nlp_small):
+    p = small_prob
+    v_ref = orc.jac_coord(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["npnts"])
+    r_ref = orc.residuals(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["pt2d"], p["npnts"])
+    rr, cc = orc.jac_structure(p["cam_idx1"], p["pnt_idx1"], p["npnts"])
+    ref = orc.mul_sparse(cc, rr, v_ref, r_ref, nlp_small.meta.nvar)  # lm.jl:57 (index arrays swapped)
+    out = nlp_small.jtprod_coo(v_ref, r_ref)
+    assert np.max(np.abs(out - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+def test_f32_twins(ba, orc, small_prob, gpu_ok):
+    p = small_prob
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p, np.float32), T=np.float32)
+    x = p["x0"].astype(np.float32)
+    r = m.cons(x)
+    r_ref = orc.residuals(p["cam_idx1"], p["pnt_idx1"], x, p["pt2d"].astype(np.float32), p["npnts"])
+    assert r.dtype == np.float32
+    # Float32 ulp of |proj| ~ 1e3 is 6e-5; the device evaluates sin/cos in double and rounds like Julia
+    assert np.max(np.abs(r - r_ref)) <= 64 * 1.2e-7 * np.max(np.abs(r_ref + p["pt2d"]))
+    v = m.jac_coord(x).reshape(-1, 24)
+    v_ref = orc.jac_coord(p["cam_idx1"], p["pnt_idx1"], x, p["npnts"]).reshape(-1, 24)
+    assert v.dtype == np.float32
+    rel = np.abs(v - v_ref).max(1) / np.abs(v_ref).max(1)
+    assert rel.max() <= 1e-4
+    m.close()
+
+
+def test_edge_cases(ba, orc, gpu_ok):
+    # empty problem
+    m = ba.BALNLPModel(arrays=(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0), np.zeros(12), 1, 1, 0))
+    assert m.cons(np.zeros(12)).shape == (0,)
+    assert m.jac_coord(np.zeros(12)).shape == (0,)
+    m.close()
+    # theta = 0 and z = 0: NaN residual, zero Jacobian block (src/BALNLPModels.jl:19-31,201)
+    cam = np.array([1, 2], dtype=np.int64)
+    pnt = np.array([1, 1], dtype=np.int64)
+    x = np.array([0.1, 0.2, 0.0,
+                  0, 0, 0, 0, 0, -5.0, 1e-7, 1e-12, 500.0,
+                  0, 0, 0.3, 0, 0, 0.0, 1e-7, 1e-12, 500.0])
+    m = ba.BALNLPModel(arrays=(cam, pnt, np.zeros(4), x, 2, 1, 2))
+    r = m.cons(x)
+    v = m.jac_coord(x)
+    assert np.all(np.isnan(r[:2])) and not np.any(np.isfinite(r[2:]))
+    assert np.all(v == 0)
+    assert np.all(orc.jac_coord(cam, pnt, x, 1) == 0)
+    m.close()
+    # out-of-range index is refused, not a device fault
+    with pytest.raises(ba.BAError):
+        ba.BALNLPModel(arrays=(np.array([3], np.int64), np.array([1], np.int64), np.zeros(2), np.zeros(21), 2, 1, 1))
+
+
+def test_unsorted_observations(ba, orc, small_prob, gpu_ok):
+    """Ragged / shuffled observation order (not BAL order): every entry point must still agree."""
+    p = small_prob
+    perm = np.random.default_rng(3).permutation(p["nobs"])
+    cam, pnt = p["cam_idx1"][perm], p["pnt_idx1"][perm]
+    pt2d = p["pt2d"].reshape(-1, 2)[perm].ravel()
+    m = ba.BALNLPModel(arrays=(cam, pnt, pt2d, p["x0"], p["ncams"], p["npnts"], p["nobs"]))
+    r_ref = orc.residuals(cam, pnt, p["x0"], pt2d, p["npnts"])
+    v_ref = orc.jac_coord(cam, pnt, p["x0"], p["npnts"])
+    rr, cc = orc.jac_structure(cam, pnt, p["npnts"])
+    assert np.array_equal(m.jac_structure()[1], cc)
+    out = m.jtprod_coo(v_ref, r_ref)
+    ref = orc.mul_sparse(cc, rr, v_ref, r_ref, m.meta.nvar)
+    assert np.max(np.abs(out - ref)) <= 1e-12 * np.max(np.abs(ref))
+    d, half, _ = ba.lm_step(m, p["x0"], 10.0)
+    rc, d_ref, dr_ref, _ = orc.lm_step(p["ncams"], p["npnts"], cam, pnt, pt2d, p["x0"], 10.0)
+    assert rc == 0
+    assert np.linalg.norm(d - d_ref) <= 1e-9 * np.linalg.norm(d_ref)
+    m.close()
+
+
+@pytest.mark.parametrize("n", [5, 128, 200, 441, 700])
+def test_dense_ldl_vs_numpy(ba, n, gpu_ok):
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n + 8))
+    A = G @ G.T + 0.5 * np.eye(n)
+    # asymmetric right-hand side and a matrix with no special structure: a transposed fragment layout cannot pass
+    b = rng.standard_normal(n)
+    x, ms = ba._lib.dense_ldl_solve(A, b)
+    x_ref = np.linalg.solve(A, b)
+    assert np.linalg.norm(x - x_ref) <= 1e-10 * np.linalg.norm(x_ref) * np.linalg.cond(A) ** 0.5
+
+
+def test_dense_ldl_indefinite_and_zero_pivot(ba, gpu_ok):
+    # LDL' without pivoting accepts negative pivots (quasi-definite input), like src/ldl_aux.jl
+    rng = np.random.default_rng(5)
+    n = 150
+    G = rng.standard_normal((n, n))
+    A = G @ G.T + np.eye(n)
+    A[:40, :40] *= -1.0
+    A[:40, 40:] = 0.1 * A[:40, 40:]
+    A[40:, :40] = A[:40, 40:].T
+    b = rng.standard_normal(n)
+    x, _ = ba._lib.dense_ldl_solve(A, b)
+    assert np.linalg.norm(A @ x - b) <= 1e-8 * np.linalg.norm(b)
+    Z = np.eye(4)
+    Z[0, 0] = 0.0
+    with pytest.raises(ba.SQDException):
+        ba._lib.dense_ldl_solve(Z, np.ones(4))
+
+
+@pytest.mark.parametrize("lam", [1e3, 30.0, 1.0, 1e-2])
+def test_lm_step_vs_oracle(ba, orc, small_prob, nlp_small, lam):
+    p = small_prob
+    d, half, jtr = ba.lm_step(nlp_small, p["x0"], lam)
+    rc, d_ref, dr_ref, jtr_ref = orc.lm_step(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"], lam)
+    assert rc == 0
+    rel = np.linalg.norm(d - d_ref) / np.linalg.norm(d_ref)
+    print(f"lambda {lam}: |d - d_ref|/|d_ref| = {rel:.2e}")
+    assert rel <= 1e-9
+    assert abs(half - 0.5 * dr_ref @ dr_ref) <= 1e-9 * (0.5 * dr_ref @ dr_ref)
+    assert np.max(np.abs(jtr - jtr_ref)) <= 1e-12 * np.max(np.abs(jtr_ref))
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+def test_lm_solve_vs_oracle(ba, orc, small_prob, gpu_ok, variant):
+    p = small_prob
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    fr = ba.FeasibilityResidual(m)
+    if variant == 1:
+        st = ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False)
+    else:
+        st = ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None")
+    rc, x_ref, st_ref, log_ref = orc.lm_solve(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"],
+                                              variant=variant)
+    assert rc == 0
+    print(st.status, st.iter, st.objective, "oracle:", st_ref.status, st_ref.iter, st_ref.objective)
+    assert st.iter == st_ref.iter
+    assert st.status == orc.STATUS[st_ref.status]
+    assert abs(st.objective - st_ref.objective) <= 1e-8 * st_ref.objective
+    assert [r[7] for r in st.log] == [bool(v) for v in log_ref[:, 7]]
+    f_gpu = np.array([r[1] for r in st.log])
+    assert np.allclose(f_gpu, log_ref[:, 1], rtol=1e-6)
+    assert np.linalg.norm(st.solution - x_ref) <= 1e-6 * np.linalg.norm(x_ref)
+    assert m.counters.neval_jac == st.n_jacobian + 1
+    m.close()
+
+
+def test_lm_linesearch_vs_oracle(ba, orc, small_prob, gpu_ok):
+    p = small_prob
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "LDL", "Metis", "None", True, lam=1e-3)
+    rc, x_ref, st_ref, log_ref = orc.lm_solve(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"],
+                                              variant=1, linesearch=True, lam=1e-3)
+    assert rc == 0 and st.iter == st_ref.iter
+    assert abs(st.objective - st_ref.objective) <= 1e-8 * st_ref.objective
+    m.close()
+
+
+def test_reader_to_model(ba, orc, small_prob, tmp_path, gpu_ok):
+    p = small_prob
+    path = str(tmp_path / "Synth" / "problem-12-400-pre.txt.bz2")
+    ba.synthetic.write_bal(path, p)
+    m = ba.BALNLPModel(path)
+    assert (m.ncams, m.npnts, m.nobs) == (p["ncams"], p["npnts"], p["nobs"])
+    assert np.array_equal(m.meta.x0, p["x0"]) and np.array_equal(m.pt2d, p["pt2d"])
+    r = m.cons(m.meta.x0)
+    r_ref = orc.residuals(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["pt2d"], p["npnts"])
+    assert np.all(np.abs(r - r_ref) <= _res_tol(r_ref, p["pt2d"]))
+    m.close()
+
+
+def test_full_size_properties(ba, gpu_ok):
+    """BASELINE-size shape (Dubrovnik-356: 1.26 M observations): size-independent properties instead of an oracle run.
+    pattern == closed form (vectorised); J'r linear in r; residual at x_true minus noise-free projection ~ noise."""
+    p = ba.synthetic.make_named("dubrovnik-356")
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    rows, cols = m.jac_structure()
+    k = np.arange(p["nobs"])
+    assert np.array_equal(rows.reshape(-1, 24)[:, 0], 2 * k + 1) and np.array_equal(rows.reshape(-1, 24)[:, 23], 2 * k + 2)
+    assert np.array_equal(cols.reshape(-1, 24)[:, 2], 3 * (p["pnt_idx1"] - 1) + 3)
+    assert np.array_equal(cols.reshape(-1, 24)[:, 23], 3 * p["npnts"] + 9 * p["cam_idx1"])
+    assert np.array_equal(cols.reshape(-1, 24)[:, :12], cols.reshape(-1, 24)[:, 12:])
+    r = m.cons(p["x_true"])
+    assert abs(np.std(r) - 0.5) < 0.01  # pt2d = proj(x_true) + N(0, 0.5^2)
+    vals = m.jac_coord(p["x0"])
+    rng = np.random.default_rng(1)
+    a, b = rng.standard_normal(2 * p["nobs"]), rng.standard_normal(2 * p["nobs"])
+    ja, jb, jab = m.jtprod_coo(vals, a), m.jtprod_coo(vals, b), m.jtprod_coo(vals, 2 * a - 3 * b)
+    assert np.max(np.abs(jab - (2 * ja - 3 * jb))) <= 1e-11 * np.max(np.abs(jab))
+    # directional derivative: r(x + h d) - r(x - h d) ~ 2h J d, checked through d' J' w = (J d)' w
+    d = rng.standard_normal(m.meta.nvar) * 1e-3
+    h = 1e-4
+    fd = (m.cons(p["x0"] + h * d) - m.cons(p["x0"] - h * d)) / (2 * h)
+    w = rng.standard_normal(2 * p["nobs"])
+    lhs = d @ m.jtprod_coo(vals, w)
+    assert abs(lhs - fd @ w) <= 1e-5 * (np.linalg.norm(fd) * np.linalg.norm(w))
+    m.close()

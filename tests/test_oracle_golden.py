@@ -1,0 +1,103 @@
+"""The oracle (oracle/ba_oracle.c) against every golden vector / known answer the reference's own tests hold for
+this path (test/runtests.jl) and against residuals produced by the reference's Python restatement
+(src/SolverScipy.py `fun`, committed under tests/golden/ by tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+
+
+def test_runtests_residual_fixture_bit_exact(orc, fixture_runtests):
+    f = fixture_runtests  # test/runtests.jl:15-27: norm(true_residuals - r) == 0
+    r = orc.residuals(f["cam_idx"], f["pnt_idx"], f["x"], f["pt2d"], int(f["npnts"]))
+    assert np.linalg.norm(f["true_residuals"] - r) == 0
+
+
+def test_runtests_known_answers_bit_exact(orc, fixture_runtests):
+    f = fixture_runtests
+    # test/runtests.jl:6  Rodrigues_rotation([1,1,1],[2.5,-0.3,1.0])  (== P1 with t = 0)
+    rot = orc.P1(f["rodrigues_r"], np.zeros(3), f["rodrigues_x"])
+    assert np.array_equal(rot, f["rodrigues_out"])
+    # test/runtests.jl:8  projection(x,y,z, rx,ry,rz, tx,ty,tz, f,k1,k2) == [-7 -7]
+    a = f["projection_args"]
+    cam = np.array([a[3], a[4], a[5], a[6], a[7], a[8], a[10], a[11], a[9]])  # (r, t, k1, k2, f)
+    assert np.array_equal(orc.projection(a[:3], cam), f["projection_out"])
+    # test/runtests.jl:7  scaling_factor([1 1], 1, 1) == 7: the origin rotates to exactly 0, so P1 = t = (-1,-1,1),
+    # P2 = (1,1) and projection = f * scaling * P2 = (7,7) for f = 1
+    cam = np.array([1.0, 1.0, 1.0, -1.0, -1.0, 1.0, 1.0, 1.0, 1.0])
+    out = orc.projection(np.zeros(3), cam)
+    assert np.array_equal(out, np.array([7.0, 7.0]))
+
+
+def test_residuals_match_reference_python_bit_exact(orc, golden_scipy):
+    g = golden_scipy
+    for tag in ("x0", "xtrue"):
+        x = g["x0"] if tag == "x0" else g["x_true"]
+        r = orc.residuals(g["cam_idx1"], g["pnt_idx1"], x, g["pt2d"], int(g["npnts"]))
+        assert np.array_equal(r, g["res_" + tag])
+
+
+def test_f32_twin_close_to_f64(orc, golden_scipy):
+    g = golden_scipy
+    r64 = orc.residuals(g["cam_idx1"], g["pnt_idx1"], g["x0"], g["pt2d"], int(g["npnts"]))
+    r32 = orc.residuals(g["cam_idx1"], g["pnt_idx1"], g["x0"].astype(np.float32), g["pt2d"].astype(np.float32),
+                        int(g["npnts"]))
+    assert r32.dtype == np.float32
+    assert np.max(np.abs(r32 - r64)) < 0.5  # pixels; Float32 carries ~1e-4 relative on |proj| ~ 1e3
+
+
+def test_jac_structure_closed_form(orc, small_prob):
+    p = small_prob
+    rows, cols = orc.jac_structure(p["cam_idx1"], p["pnt_idx1"], p["npnts"])
+    k = np.arange(p["nobs"])
+    exp_rows = np.repeat(np.stack([2 * k + 1, 2 * k + 2], 1), 12, axis=1).reshape(-1)
+    pc = 3 * (p["pnt_idx1"] - 1)[:, None] + 1 + np.arange(3)[None, :]
+    cc = 3 * p["npnts"] + 9 * (p["cam_idx1"] - 1)[:, None] + 1 + np.arange(9)[None, :]
+    one = np.concatenate([pc, cc], 1)
+    exp_cols = np.concatenate([one, one], 1).reshape(-1)
+    assert np.array_equal(rows, exp_rows) and np.array_equal(cols, exp_cols)
+    assert rows.dtype == np.int64 and rows.min() == 1 and cols.max() == 3 * p["npnts"] + 9 * p["ncams"]
+
+
+def _complex_step_block(X, C):
+    """Independent derivative of the pinned projection (complex step, h = 1e-30): 2x12 in column order
+    [X, r, t, k1, k2, f]."""
+    def proj(X, C):
+        r, t, k1, k2, f = C[:3], C[3:6], C[6], C[7], C[8]
+        th = np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2])
+        k = r / th
+        c, s = np.cos(th), np.sin(th)
+        kx = np.array([k[1] * X[2] - k[2] * X[1], k[2] * X[0] - k[0] * X[2], k[0] * X[1] - k[1] * X[0]])
+        d = k[0] * X[0] + k[1] * X[1] + k[2] * X[2]
+        P1 = c * X + s * kx + (1 - c) * d * k + t
+        P2 = -P1[:2] / P1[2]
+        n = P2[0] * P2[0] + P2[1] * P2[1]
+        return f * (1.0 + k1 * n + k2 * n * n) * P2
+    v = np.concatenate([X, C]).astype(complex)
+    J = np.zeros((2, 12))
+    for j in range(12):
+        w = v.copy()
+        w[j] += 1e-30j
+        J[:, j] = proj(w[:3], w[3:]).imag / 1e-30
+    return J
+
+
+def test_jac_coord_is_the_true_derivative(orc, small_prob):
+    p = small_prob
+    vals = orc.jac_coord(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["npnts"]).reshape(-1, 2, 12)
+    x = p["x0"]
+    rng = np.random.default_rng(0)
+    for k in rng.choice(p["nobs"], size=40, replace=False):
+        X = x[3 * (p["pnt_idx1"][k] - 1): 3 * p["pnt_idx1"][k]]
+        C = x[3 * p["npnts"] + 9 * (p["cam_idx1"][k] - 1): 3 * p["npnts"] + 9 * p["cam_idx1"][k]]
+        Jcs = _complex_step_block(X, C)
+        assert np.max(np.abs(vals[k] - Jcs)) <= 1e-11 * np.max(np.abs(Jcs))
+
+
+def test_jac_coord_nan_to_zero(orc):
+    # theta = 0 (r = 0) -> every entry NaN in the reference -> 0 (src/BALNLPModels.jl:201)
+    cam = np.array([1], dtype=np.int64)
+    x = np.array([0.1, 0.2, 0.3, 0, 0, 0, 0, 0, -5.0, 1e-7, 1e-12, 500.0])
+    assert np.all(orc.jac_coord(cam, cam, x, 1) == 0)
+    assert np.all(np.isnan(orc.residuals(cam, cam, x, np.zeros(2), 1)))
+    # P1.z = 0 -> NaN block -> 0; the residual itself is +-Inf/NaN (no guard in the reference)
+    x = np.array([0.1, 0.2, 0.0, 0, 0, 0.3, 0, 0, 0.0, 1e-7, 1e-12, 500.0])  # rotation about z keeps P1.z = t_z = 0 exactly
+    v = orc.jac_coord(cam, cam, x, 1)
+    assert np.all(v == 0)
