@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/s (+ Jacobian Mnnz/s) of the MI355X hot path on a synthetic BAL-shaped problem.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one Levenberg-Marquardt iteration of src/lm.jl (factor + solve of the damped normal equations, trial
+residual, accept/reject; accepted steps add a Jacobian refresh), run with all stopping tolerances at zero so that
+exactly K iterations execute.  Workload at every N: Venice-1778-993923-shaped synthetic data (BASELINE.json's metric),
+observations sharded by point over the N ranks, cameras replicated => "strong" scaling.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import os
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # oracle baseline: idle OpenMP threads must not spin
+import ctypes as C
+import json
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F64_PEAK_TF = 78.6    # MI355X FP64 matrix peak (vendor sheet; v_mfma_f64_16x16x4_f64, 2048 flop / 64 clk / SIMD)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="venice-1778")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only; invalid as a result)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def lm_fixed_iterations(ba, fr, k, x=None):
+    """exactly k iterations of lm.jl: every stopping test disabled except the iteration cap"""
+    return ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False, x=x, ite_max=k - 1, restol=0.0, satol=0.0, srtol=0.0,
+                                  oatol=0.0, ortol=0.0, atol=0.0, rtol=0.0, log=False)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    ba = ge.load_package()
+
+    # ---- workload ---------------------------------------------------------------------------------------------------
+    t0 = time.time()
+    prob = ba.synthetic.make_named(args.workload, scale=args.scale)
+    arrays = ba.synthetic.as_arrays(prob)
+    if world > 1:
+        arrays, info = ba.parallel.shard_problem(arrays, rank, world)
+    nlp = ba.BALNLPModel(arrays=arrays, device=local_rank, model_name=args.workload)
+    fr = ba.FeasibilityResidual(nlp)
+    reducer = ba.parallel.CameraBlockReducer(nlp) if world > 1 else None
+    t_setup = time.time() - t0
+    nobs_g, npnts_g, ncams = prob["nobs"], prob["npnts"], prob["ncams"]
+    nvar_g = 3 * npnts_g + 9 * ncams
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup (also allocates the LM workspace and builds the Schur task list) ---------------------------------------
+    if args.warmup > 0:
+        lm_fixed_iterations(ba, fr, args.warmup)
+    barrier()
+    t1 = time.perf_counter()
+    st = lm_fixed_iterations(ba, fr, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert st.iter == args.steps, (st.iter, args.steps)
+
+    # ---- Jacobian throughput: jac_coord on device-resident x / vals, events on the launch stream ---------------------
+    stream = torch.cuda.Stream()  # a real (non-null) stream: the library treats a null stream as "the handle's own"
+    x_dev = torch.from_numpy(np.ascontiguousarray(arrays[3])).cuda()
+    vals_dev = torch.empty(24 * nlp.nobs, dtype=torch.float64, device="cuda")
+    L = ba._lib.lib()
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def jac():
+        ba._lib.check(L.ba_jac_coord_dev(nlp.handle, C.c_void_p(x_dev.data_ptr()), C.c_void_p(vals_dev.data_ptr()), sp))
+
+    torch.cuda.synchronize()
+    for _ in range(3):
+        jac()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    e0.record(stream)
+    for _ in range(reps):
+        jac()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    jac_ms = e0.elapsed_time(e1) / reps
+    if world > 1:
+        t = torch.tensor([jac_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        jac_ms = float(t.item())
+    jac_mnnz = 24.0 * nobs_g / (jac_ms * 1e-3) / 1e6
+    # algorithmic bytes of jac_coord!: 2 int64 indices + 24 doubles out + every parameter read once
+    jac_bytes = (208.0 + 8.0 * nvar_g / nobs_g) * nobs_g / world
+    jac_gbs = jac_bytes / (jac_ms * 1e-3) / 1e9
+
+    # ---- per-kernel profile of the same K iterations (separate, synchronising run) ---------------------------------------
+    prof = {}
+    if not args.no_profile:
+        nlp.profile(True)
+        lm_fixed_iterations(ba, fr, args.steps)
+        prof = nlp.profile_get()
+        nlp.profile(False)
+    roof = None
+    if prof:
+        name, (ms, calls) = max(prof.items(), key=lambda kv: kv[1][0])
+        n_fact = max(1, prof["k_ldl_diag"][1] // max(1, (9 * ncams + 127) // 128))
+        if name == "k_ldl_syrk":
+            nt = (9 * ncams + 127) // 128
+            tiles = sum((nt - k - 1) * (nt - k) // 2 for k in range(nt))
+            flops = n_fact * tiles * 2.0 * 128 ** 3
+            ach = flops / (ms * 1e-3) / 1e12
+            roof = dict(kernel=name, bound="mfma", achieved=ach, peak=MFMA_F64_PEAK_TF, unit="TFLOP/s",
+                        frac=ach / MFMA_F64_PEAK_TF, traffic=None, avg_launch_ms=ms / calls, launches=calls)
+        else:
+            roof = dict(kernel=name, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
+                        avg_launch_ms=ms / calls, launches=calls)
+    roof_jac = dict(kernel="k_jac_coord", bound="hbm", achieved=jac_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=jac_gbs / HBM_PEAK_GBS, traffic=None, avg_launch_ms=jac_ms,
+                    bytes_per_obs=208.0 + 8.0 * nvar_g / nobs_g)
+    if roof is None:
+        roof = roof_jac
+
+    # ---- CPU baseline: the oracle's restatement of the reference LM, bounded sample, rank 0 at N = 1 only ---------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        orc = ge.load_oracle()
+        cores = orc.lib().orc_num_threads()
+        t0 = time.time()
+        rc, _, s, _ = orc.lm_solve(prob["ncams"], prob["npnts"], prob["cam_idx1"], prob["pnt_idx1"], prob["pt2d"],
+                                   prob["x0"], variant=1, max_iter_timed=1, facto_time_cap_s=args.cpu_seconds)
+        # numeric LDL': the residual-row and point columns (head) are timed exactly; the camera columns (tail) are timed
+        # for --cpu-seconds and extrapolated by their multiply-add count
+        w_tail_total = s.facto_work_total - s.facto_work_head
+        w_tail_done = s.facto_work_done - s.facto_work_head
+        t_tail_done = s.t_facto - s.t_facto_head
+        frac = w_tail_done / w_tail_total if w_tail_total > 0 else 1.0
+        t_fact = s.t_facto_head + (t_tail_done / max(frac, 1e-12) if frac < 1.0 else t_tail_done)
+        rate = w_tail_done / max(t_tail_done, 1e-9)
+        t_solve = s.t_solve if s.t_solve > 0 else 2.0 * s.lnz / rate  # L and L' sweeps when the solve never ran
+        t_sparse = s.t_assemble / s.n_sparse if s.n_sparse else s.t_analyse * 0.0
+        # one accepted iteration of the reference = factor + solve + residual + Jacobian + sparse() + J'r
+        t_iter = t_fact + t_solve + s.t_residual / max(1, s.n_res) + s.t_jac / max(1, s.n_jac) + s.t_jtr + t_sparse
+        cpu = dict(value=1.0 / t_iter, unit="LM iterations/s", cores=cores, kind="port",
+                   sample=(f"1 LM iteration of oracle/ba_oracle.c (restated lm.jl + ldl_aux.jl, structured elimination order) "
+                           f"on the full {args.workload} shape: residual/Jacobian/J'r and the residual-row + point columns of the "
+                           f"numeric LDL' ({s.t_facto_head:.1f}s) timed exactly, its camera columns stopped after {t_tail_done:.1f}s = "
+                           f"{100 * frac:.3g}% of their multiply-adds and extrapolated by multiply-add count (symbolic analysis "
+                           f"{s.t_analyse:.0f}s, one-off, excluded); residual on {cores} threads, Jacobian on {min(3, cores)}, "
+                           f"factorisation on 1"),
+                   jacobian_mnnz_per_s=24.0 * nobs_g / (s.t_jac / max(1, s.n_jac)) / 1e6,
+                   t_factor_s=t_fact, factor_fraction_timed=frac, lnz=int(s.lnz), wall_s=time.time() - t0)
+
+    if rank == 0:
+        out = {
+            "metric": "LM iterations/sec on BAL Venice-1778 (synthetic BAL-shaped), plus Jacobian Mnnz/sec",
+            "value": args.steps / elapsed,
+            "unit": "LM iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload} shape: ncams={ncams} npnts={npnts_g} nobs={nobs_g}, seed "
+                                   f"{ba.synthetic.BASE_SEED}, lm.jl variant, LDL/None, fixed {args.steps} iterations"
+                                   + ("" if args.scale == 1.0 else f" SCALED x{args.scale} (debug)"),
+                       "parallelism": f"points sharded over {world} rank(s), cameras replicated"},
+            "jacobian_mnnz_per_s": jac_mnnz,
+            "jacobian_ms": jac_ms,
+            "lm": {"accepted": st.n_accepted, "rejected": st.n_rejected, "objective": st.objective,
+                   "n_jacobian": st.n_jacobian, "n_factor": st.n_factor, "loop_s": st.loop_time},
+            "roofline": roof,
+            "roofline_jacobian": roof_jac,
+            "cpu_baseline": cpu,
+            "kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1] > 0},
+            "setup_s": t_setup,
+        }
+        if reducer is not None:
+            out["comm"] = {"allreduce_calls": reducer.calls, "allreduce_bytes": reducer.bytes}
+        print(json.dumps(out))
+    nlp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

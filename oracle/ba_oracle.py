@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+# libgomp's default active spinning starves the (single-threaded) factorisation under a CPU quota: idle threads sleep.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -36,7 +38,8 @@ class LMStats(C.Structure):
                 ("t_facto", C.c_double), ("t_solve", C.c_double), ("t_jtr", C.c_double),
                 ("n_facto", C.c_int), ("n_jac", C.c_int), ("n_res", C.c_int),
                 ("lnz", C.c_int64), ("facto_work_total", C.c_double), ("facto_work_done", C.c_double),
-                ("n_log", C.c_int)]
+                ("n_log", C.c_int), ("n_sparse", C.c_int), ("t_analyse", C.c_double),
+                ("t_facto_head", C.c_double), ("facto_work_head", C.c_double)]
 
 
 def build():

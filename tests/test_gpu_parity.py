@@ -1,8 +1,10 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle.  Needs an MI355X: run with -m gpu.
 Tolerances (stated, fp64):
   * Jacobian pattern: bit-exact int64.
-  * residuals: |r_gpu - r_oracle| <= 32 ulp of max(|proj|, 1)  (device sin/cos/sqrt/div differ from libm in the last
-    bits; the reference's own fixture, test/runtests.jl:27, is therefore matched to that bound, not to 0).
+  * residuals: |r_gpu - r_oracle| <= eps * (8 |proj| + f / 2), f the camera's focal length: rounding differences in
+    P1 (device sin/cos/sqrt/div differ from libm in the last bits) are amplified by f / |z| into pixels, so the error
+    scale of a small coordinate is f, not the coordinate itself.  The reference's own fixture, test/runtests.jl:27, is
+    matched to that bound, not to 0.
   * Jacobian values: <= 1e-12 relative to the inf-norm of the 2x12 block.
   * J'r: <= 1e-12 relative to max|J'r| (different, but fixed, summation order).
   * one LM step from identical (x, lambda): |delta - delta_ref| / |delta_ref| <= 1e-9 for lambda >= 1e-2 on the
@@ -23,8 +25,12 @@ def nlp_small(ba, small_prob, gpu_ok):
     m.close()
 
 
-def _res_tol(r_ref, pt2d):
-    return 32 * EPS * np.maximum(np.abs(r_ref + pt2d), 1.0)
+def _focal(x, cam_idx1, npnts):
+    return np.repeat(np.abs(np.asarray(x)[3 * npnts + 9 * (np.asarray(cam_idx1) - 1) + 8]), 2)
+
+
+def _res_tol(r_ref, pt2d, f):
+    return EPS * (8 * np.abs(r_ref + pt2d) + 0.5 * f)
 
 
 def test_library_is_the_hip_one(ba, gpu_ok):
@@ -38,7 +44,7 @@ def test_runtests_fixture_through_c_abi(ba, fixture_runtests, gpu_ok):
     f = fixture_runtests
     m = ba.BALNLPModel(arrays=(f["cam_idx"], f["pnt_idx"], f["pt2d"], f["x"], 5, 1, 5))
     r = m.cons(f["x"])
-    assert np.all(np.abs(r - f["true_residuals"]) <= _res_tol(f["true_residuals"], f["pt2d"]))
+    assert np.all(np.abs(r - f["true_residuals"]) <= _res_tol(f["true_residuals"], f["pt2d"], _focal(f["x"], f["cam_idx"], 1)))
     m.close()
 
 
@@ -48,7 +54,7 @@ def test_residual_matches_reference_python_golden(ba, golden_scipy, gpu_ok):
                                len(g["cam_idx1"])))
     for tag, x in (("x0", g["x0"]), ("xtrue", g["x_true"])):
         r = m.cons(x)
-        assert np.all(np.abs(r - g["res_" + tag]) <= _res_tol(g["res_" + tag], g["pt2d"]))
+        assert np.all(np.abs(r - g["res_" + tag]) <= _res_tol(g["res_" + tag], g["pt2d"], _focal(x, g["cam_idx1"], int(g["npnts"]))))
     m.close()
 
 
@@ -56,9 +62,9 @@ def test_residual_vs_oracle(ba, orc, small_prob, nlp_small):
     p = small_prob
     r = nlp_small.cons(p["x0"])
     r_ref = orc.residuals(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["pt2d"], p["npnts"])
-    err = np.abs(r - r_ref) / np.maximum(np.abs(r_ref + p["pt2d"]), 1.0) / EPS
-    print("residual max err [ulp of proj]:", err.max())
-    assert err.max() <= 32
+    err = np.abs(r - r_ref) / _res_tol(r_ref, p["pt2d"], _focal(p["x0"], p["cam_idx1"], p["npnts"]))
+    print("residual max err / tolerance:", err.max())
+    assert err.max() <= 1
 
 
 def test_jac_structure_bit_exact(ba, orc, small_prob, nlp_small):
@@ -236,7 +242,7 @@ def test_reader_to_model(ba, orc, small_prob, tmp_path, gpu_ok):
     assert np.array_equal(m.meta.x0, p["x0"]) and np.array_equal(m.pt2d, p["pt2d"])
     r = m.cons(m.meta.x0)
     r_ref = orc.residuals(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["pt2d"], p["npnts"])
-    assert np.all(np.abs(r - r_ref) <= _res_tol(r_ref, p["pt2d"]))
+    assert np.all(np.abs(r - r_ref) <= _res_tol(r_ref, p["pt2d"], _focal(p["x0"], p["cam_idx1"], p["npnts"])))
     m.close()
 
 
