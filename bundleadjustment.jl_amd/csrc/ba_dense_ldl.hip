@@ -19,64 +19,130 @@
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int LDA = NB + 1;  // LDS row stride of the diagonal-tile kernel (bank-conflict padding)
-constexpr int KC = 32;       // K chunk of the GEMM kernels staged through LDS
-constexpr int LDK = KC + 2;  // row stride 68 dwords: 4i+2k distinct banks for the MFMA operand reads
-constexpr size_t DIAG_LDS = (size_t)NB * LDA * sizeof(double);
+constexpr int KC = 16;       // K chunk of the GEMM kernels staged through LDS
+constexpr int LDK = KC + 2;  // row stride 36 dwords: 36i+2k hit distinct banks for the MFMA operand reads
 constexpr size_t GEMM_LDS = (size_t)2 * NB * LDK * sizeof(double);
 
 // v_mfma_f64_16x16x4_f64 C/D layout: lane l, result register g hold C[row][l & 15]
 __device__ inline int mfma_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 
 // ---- diagonal tile ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_ldl_diag(double *__restrict__ Skk, double *__restrict__ Linv_k,
-                                                    double *__restrict__ D_k, int *__restrict__ flag) {
-  extern __shared__ double a[];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < NB * NB; idx += 1024) {
+// One workgroup (4 waves) factors the 128x128 tile in LDS as 8x8 blocks of 16x16:
+//   for each block column jb: unblocked LDL' of the 16x16 diagonal block, its unit-lower inverse (16 lanes, registers),
+//   X(I) = A(I,jb) Linv16' by MFMA (kept unscaled: X = L D), trailing blocks C(I,J) -= X(I) (X(J) D^-1)' by MFMA;
+// then the full unit-lower inverse of the tile by block forward substitution (MFMA), stored transposed in the
+// upper triangle of the LDS image.  Writes L (scaled, D on the diagonal) back in place, Linv and D.
+constexpr int LDA2 = 130;  // row stride 260 dwords = 4 mod 64: conflict-free MFMA operand reads
+constexpr int XDL = 18;
+constexpr size_t DIAG_LDS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB) * sizeof(double);
+
+__global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, double *__restrict__ Linv_k,
+                                                   double *__restrict__ D_k, int *__restrict__ flag) {
+  extern __shared__ double sm[];
+  double *a = sm, *xd = sm + NB * LDA2, *dd = xd + 8 * 16 * XDL, *dinv = dd + NB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int idx = tid; idx < NB * NB; idx += 256) {
     int i = idx >> 7, j = idx & (NB - 1);
-    a[i * LDA + j] = (j <= i) ? Skk[idx] : 0.0;
+    a[i * LDA2 + j] = (j <= i) ? Skk[idx] : 0.0;
   }
+  for (int idx = tid; idx < 8 * 16 * XDL; idx += 256) xd[idx] = 0.0;
   __syncthreads();
-  const int row = tid >> 3, sub = tid & 7;
-  for (int j = 0; j < NB; j++) {
-    const double d = a[j * LDA + j];
-    const double inv_d = 1.0 / d;
-    if (tid == 0) {
-      D_k[j] = d;
-      if (d == 0.0) *flag = 1;
+  for (int jb = 0; jb < 8; jb++) {
+    const int o = 16 * jb;
+    double *xj = xd + jb * 16 * XDL;
+    {  // unblocked LDL' of the diagonal block, one element per thread
+      const int i = tid >> 4, c = tid & 15;
+      for (int j = 0; j < 16; j++) {
+        const double d = a[(o + j) * LDA2 + o + j];
+        const double inv = 1.0 / d;
+        if (i > j && c > j && c <= i) a[(o + i) * LDA2 + o + c] -= a[(o + i) * LDA2 + o + j] * inv * a[(o + c) * LDA2 + o + j];
+        if (tid == 0) {
+          dd[o + j] = d;
+          dinv[o + j] = inv;
+          if (d == 0.0) *flag = 1;
+        }
+        __syncthreads();
+      }
     }
-    if (row > j) {
-      const double lij = a[row * LDA + j] * inv_d;
-      for (int c = j + 1 + sub; c <= row; c += 8) a[row * LDA + c] -= lij * a[c * LDA + j];
+    if (tid < 16) {  // column tid of the inverse of the unit-lower block, l[i][m] = a[i][m] * dinv[m]
+      const int c = tid;
+      double y[16];  // y[m] = dinv[m] * x[m]
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        double s = 0;
+#pragma unroll
+        for (int m = 0; m < i; m++) s += a[(o + i) * LDA2 + o + m] * y[m];
+        const double x = (i < c) ? 0.0 : (i == c ? 1.0 : -s);
+        y[i] = x * dinv[o + i];
+        xj[i * XDL + c] = x;
+      }
     }
     __syncthreads();
-    if (sub == 0 && row > j) a[row * LDA + j] *= inv_d;  // column j is final; nobody reads it again in this loop
-  }
-  __syncthreads();
-  // X = L^-1 (unit lower): X[m][c], m > c, kept at a[c][m] (upper half).  8 lanes per column, all in one wave.
-  {
-    const int c = tid >> 3;
-    for (int i = c + 1; i < NB; i++) {
-      double s = 0;
-      for (int m = c + 1 + sub; m < i; m += 8) s += a[i * LDA + m] * a[c * LDA + m];
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if (sub == 0) a[c * LDA + i] = -(a[i * LDA + c] + s);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    // X(I) = A(I,jb) * Linv16'
+    for (int I = jb + 1 + wv; I < 8; I += 4) {
+      d4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(16 * I + fr) * LDA2 + o + 4 * kk + fk], xj[fr * XDL + 4 * kk + fk], acc,
+                                                   0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; g++) a[(16 * I + mfma_row(lane, g)) * LDA2 + o + fr] = acc[g];
     }
+    __syncthreads();
+    // C(I,J) -= X(I) * (X(J) D^-1)'
+    const int mb = 7 - jb, nblk = mb * (mb + 1) / 2;
+    for (int t = wv; t < nblk; t += 4) {
+      int ii = 0;
+      while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+      const int jj = t - ii * (ii + 1) / 2;
+      const int I = jb + 1 + ii, J = jb + 1 + jj;
+      d4 acc;
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc[g] = a[(16 * I + mfma_row(lane, g)) * LDA2 + 16 * J + fr];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int k = o + 4 * kk + fk;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[(16 * I + fr) * LDA2 + k], a[(16 * J + fr) * LDA2 + k] * dinv[k], acc, 0, 0,
+                                                   0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g++) a[(16 * I + mfma_row(lane, g)) * LDA2 + 16 * J + fr] = acc[g];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int idx = tid; idx < NB * NB; idx += 1024) {
-    int i = idx >> 7, j = idx & (NB - 1);
+  // full inverse: X(I,J) = -Linv16(I) * sum_{K=J}^{I-1} L(I,K) X(K,J); X(I,J)[i][j] kept at a[16J+j][16I+i]
+  for (int I = 1; I < 8; I++) {
+    for (int J = wv; J < I; J += 4) {
+      d4 acc = {0, 0, 0, 0};
+      for (int K = J; K < I; K++) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const int k = 16 * K + 4 * kk + fk;
+          const double af = a[(16 * I + fr) * LDA2 + k] * dinv[k];
+          const double bf = (K == J) ? xd[(J * 16 + 4 * kk + fk) * XDL + fr] : a[(16 * J + fr) * LDA2 + k];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+        }
+      }
+      d4 out = {0, 0, 0, 0};
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        out = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[(I * 16 + fr) * XDL + 4 * g + fk], acc[g], out, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; g++) a[(16 * J + fr) * LDA2 + 16 * I + mfma_row(lane, g)] = -out[g];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int i = idx >> 7, c = idx & (NB - 1);
     double l, x;
-    if (j < i) {
-      l = a[i * LDA + j];
-      x = a[j * LDA + i];
-    } else if (j == i) {
-      l = a[i * LDA + i];  // D on the diagonal of the stored tile (informative only)
+    if (c < i) {
+      l = a[i * LDA2 + c] * dinv[c];
+      x = ((i >> 4) == (c >> 4)) ? xd[((i >> 4) * 16 + (i & 15)) * XDL + (c & 15)] : a[c * LDA2 + i];
+    } else if (c == i) {
+      l = dd[i];  // D on the diagonal of the stored tile (informative only)
       x = 1.0;
     } else {
       l = 0.0;
@@ -85,28 +151,51 @@ __global__ __launch_bounds__(1024) void k_ldl_diag(double *__restrict__ Skk, dou
     Skk[idx] = l;
     Linv_k[idx] = x;
   }
+  if (tid < NB) D_k[tid] = dd[tid];
 }
 
-// ---- 128x128x128 tile product C = A * B' on the matrix cores ------------------------------------------------------
-// A, B: contiguous row-major tiles in global memory.  256 threads = 4 waves, wave w owns the 64x64 quadrant
-// (w >> 1, w & 1) as 4x4 MFMA blocks.
-__device__ inline void tile_gemm_abt(const double *__restrict__ A, const double *__restrict__ B, double *sA, double *sB,
+// ---- 128 x 128 x (128 NP) tile product C = sum_p A_p * B_p' on the matrix cores ------------------------------------
+// A_p, B_p: contiguous row-major 128x128 tiles in global memory.  256 threads = 4 waves, wave w owns the 64x64
+// quadrant (w >> 1, w & 1) as 4x4 MFMA blocks (128 accumulator VGPRs).  K is consumed in chunks of KC = 16 staged
+// through one LDS buffer (row stride 18 doubles: conflict-free operand reads); the global loads of chunk c+1 are in
+// flight (registers) while chunk c is multiplied, and two workgroups per CU cover each other's barriers.
+template <int NP>
+__device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double *__restrict__ B0,
+                                     const double *__restrict__ A1, const double *__restrict__ B1, double *sA, double *sB,
                                      d4 acc[4][4]) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
   const int fr = lane & 15, fk = lane >> 4;
-  for (int k0 = 0; k0 < NB; k0 += KC) {
+  constexpr int NLD = (NB * KC / 2) / 256;  // 16-byte loads per thread per operand per chunk
+  d2 pa[NLD], pb[NLD];
+  constexpr int UPR = KC / 2;                 // 16-byte units per row of a chunk
+  constexpr int RPS = 256 / UPR;              // rows covered by one step of the 256 threads
+  const int lrow = tid / UPR, lc2 = tid % UPR;  // thread's first (row, 16-byte column) of a chunk
+#pragma unroll
+  for (int it = 0; it < NLD; it++) {
+    pa[it] = *reinterpret_cast<const d2 *>(A0 + (lrow + RPS * it) * NB + 2 * lc2);
+    pb[it] = *reinterpret_cast<const d2 *>(B0 + (lrow + RPS * it) * NB + 2 * lc2);
+  }
+  constexpr int NCH = NP * (NB / KC);
+  for (int ch = 0; ch < NCH; ch++) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < (NB * KC / 2) / 256; it++) {
-      int idx = it * 256 + tid;
-      int row = idx >> 4, c2 = idx & 15;
-      double2 va = *reinterpret_cast<const double2 *>(A + row * NB + k0 + 2 * c2);
-      double2 vb = *reinterpret_cast<const double2 *>(B + row * NB + k0 + 2 * c2);
-      *reinterpret_cast<double2 *>(sA + row * LDK + 2 * c2) = va;
-      *reinterpret_cast<double2 *>(sB + row * LDK + 2 * c2) = vb;
+    for (int it = 0; it < NLD; it++) {
+      *reinterpret_cast<d2 *>(sA + (lrow + RPS * it) * LDK + 2 * lc2) = pa[it];
+      *reinterpret_cast<d2 *>(sB + (lrow + RPS * it) * LDK + 2 * lc2) = pb[it];
     }
     __syncthreads();
+    if (ch + 1 < NCH) {
+      const int nx = ch + 1;
+      const double *A = (NP == 2 && nx >= NB / KC) ? A1 : A0;
+      const double *B = (NP == 2 && nx >= NB / KC) ? B1 : B0;
+      const int k0 = (nx & (NB / KC - 1)) * KC;
+#pragma unroll
+      for (int it = 0; it < NLD; it++) {
+        pa[it] = *reinterpret_cast<const d2 *>(A + (lrow + RPS * it) * NB + k0 + 2 * lc2);
+        pb[it] = *reinterpret_cast<const d2 *>(B + (lrow + RPS * it) * NB + k0 + 2 * lc2);
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < KC / 4; kk++) {
       double af[4], bf[4];
@@ -123,8 +212,8 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A, const double 
 }
 
 // X_i = S_ik * Linv_k'  ->  V_i = X_i,  S_ik = X_i * D_k^-1      (i = k+1+blockIdx.x)
-__global__ __launch_bounds__(256) void k_ldl_trsm(double *__restrict__ S, const double *__restrict__ Linv_k,
-                                                   const double *__restrict__ D_k, double *__restrict__ V, int k) {
+__global__ __launch_bounds__(256, 2) void k_ldl_trsm(double *__restrict__ S, const double *__restrict__ Linv_k,
+                                                      const double *__restrict__ D_k, double *__restrict__ V, int k) {
   extern __shared__ double lds[];
   double *sA = lds, *sB = lds + NB * LDK;
   const int i = k + 1 + blockIdx.x;
@@ -135,9 +224,10 @@ __global__ __launch_bounds__(256) void k_ldl_trsm(double *__restrict__ S, const 
   for (int m = 0; m < 4; m++)
 #pragma unroll
     for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
-  tile_gemm_abt(Sik, Linv_k, sA, sB, acc);
-  __syncthreads();  // every wave has finished reading Sik through LDS staging before it is overwritten
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  tile_gemm_abt<1>(Sik, Linv_k, nullptr, nullptr, sA, sB, acc);
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
+  const int lane = tid2 & 63, wv = tid2 >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
 #pragma unroll
   for (int n = 0; n < 4; n++) {
@@ -155,26 +245,57 @@ __global__ __launch_bounds__(256) void k_ldl_trsm(double *__restrict__ S, const 
   }
 }
 
-// S_ij -= V_i * L_jk'   for the lower-triangular tile pairs k < j <= i
-__global__ __launch_bounds__(256) void k_ldl_syrk(double *__restrict__ S, const double *__restrict__ V, int k) {
+// Trailing updates.  MODE 0 (column): S_{i,k+1} -= V0_i L_{k+1,k}'  for i = k+1+blockIdx.x  (one panel, K = 128).
+// MODE 1 (pair):  S_ij -= V0_i L_jk' + V1_i L_{j,k+1}'  for the lower-triangular tile pairs base <= j <= i (K = 256): the
+// trailing matrix is read and written once per TWO panels, which halves its HBM traffic per flop.
+// MODE 2 (pair, the two tile columns base and base+1 only): what the next two panels need first (look-ahead).
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, const double *__restrict__ V0,
+                                                        const double *__restrict__ V1, int k, int base, int nt,
+                                                        int nblk) {
   extern __shared__ double lds[];
   double *sA = lds, *sB = lds + NB * LDK;
-  const int t = blockIdx.x;
-  int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-  while (ii * (ii + 1) / 2 > t) ii--;
-  const int jj = t - ii * (ii + 1) / 2;
-  const int i = k + 1 + ii, j = k + 1 + jj;
-  const double *Vi = V + (int64_t)i * NB * NB;
-  const double *Ljk = S + tile_index(j, k) * NB * NB;
+  int i, j;
+  if (MODE == 0) {
+    i = k + 1 + blockIdx.x;
+    j = k + 1;
+  } else if (MODE == 2) {
+    const int m = nt - base;  // tiles in column base; column base+1 has m-1
+    const int t = blockIdx.x;
+    if (t < m) {
+      i = base + t;
+      j = base;
+    } else {
+      i = base + 1 + (t - m);
+      j = base + 1;
+    }
+  } else {
+    // chunked block -> XCD map: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous
+    // range of tile rows so that V_i stays in its L2 (speed only)
+    const int per = (nblk + 7) / 8;
+    int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= nblk) return;
+    int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+    while (ii * (ii + 1) / 2 > t) ii--;
+    const int jj = t - ii * (ii + 1) / 2;
+    i = base + ii;
+    j = base + jj;
+  }
   double *Sij = S + tile_index(i, j) * NB * NB;
   d4 acc[4][4];
 #pragma unroll
   for (int m = 0; m < 4; m++)
 #pragma unroll
     for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
-  tile_gemm_abt(Vi, Ljk, sA, sB, acc);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (MODE == 0)
+    tile_gemm_abt<1>(V0 + (int64_t)i * NB * NB, S + tile_index(j, k) * NB * NB, nullptr, nullptr, sA, sB, acc);
+  else
+    tile_gemm_abt<2>(V0 + (int64_t)i * NB * NB, S + tile_index(j, k) * NB * NB, V1 + (int64_t)i * NB * NB,
+                     S + tile_index(j, k + 1) * NB * NB, sA, sB, acc);
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
+  const int lane = tid2 & 63, wv = tid2 >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
 #pragma unroll
   for (int n = 0; n < 4; n++) {
@@ -272,7 +393,11 @@ static int set_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_trsm),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_syrk),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
   g_attr_done = true;
   return BA_OK;
@@ -290,7 +415,10 @@ int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S) {
     BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)dense_ldl_tiles_doubles(n_unpadded) * sizeof(double)));
     w->own_S = true;
   }
-  BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)nt * NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(double)));  // 2 x two panels of L*D
+  BA_HIP_CHECK(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
+  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_chain, hipEventDisableTiming));
+  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_bulk, hipEventDisableTiming));
   BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(double)));
   BA_HIP_CHECK(hipMalloc((void **)&w->D, (size_t)nt * NB * 2 * sizeof(double)));  // D | y scratch
   BA_HIP_CHECK(hipMalloc((void **)&w->flag, sizeof(int)));
@@ -303,30 +431,98 @@ void dense_ldl_free(DenseLDL *w) {
   if (w->Linv) (void)hipFree(w->Linv);
   if (w->D) (void)hipFree(w->D);
   if (w->flag) (void)hipFree(w->flag);
+  if (w->side) (void)hipStreamDestroy(w->side);
+  if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
+  if (w->ev_bulk) (void)hipEventDestroy(w->ev_bulk);
   *w = DenseLDL();
 }
 
+static int launch_diag(ba_problem *p, DenseLDL *w, int k, hipStream_t st) {
+  ProfScope ps(p, PC_LDL_DIAG, st);
+  hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), DIAG_LDS, st, w->S + tile_index(k, k) * NB * NB,
+                     w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag);
+  return BA_OK;
+}
+
+static int launch_trsm(ba_problem *p, DenseLDL *w, int k, double *V, hipStream_t st) {
+  const int m = (int)w->nt - k - 1;
+  if (m <= 0) return BA_OK;
+  ProfScope ps(p, PC_LDL_TRSM, st);
+  hipLaunchKernelGGL(k_ldl_trsm, dim3(m), dim3(256), GEMM_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
+                     w->D + (int64_t)k * NB, V, k);
+  return BA_OK;
+}
+
+static int launch_col(ba_problem *p, DenseLDL *w, int k, const double *V0, hipStream_t st) {
+  const int m = (int)w->nt - k - 1;
+  if (m <= 0) return BA_OK;
+  ProfScope ps(p, PC_LDL_SYRK, st);
+  hipLaunchKernelGGL(k_ldl_update<0>, dim3(m), dim3(256), GEMM_LDS, st, w->S, V0, V0, k, k + 1, (int)w->nt, m);
+  return BA_OK;
+}
+
+// pair update of the tile columns >= base with panels k, k+1 (first2: only columns base and base+1)
+static int launch_pair(ba_problem *p, DenseLDL *w, int k, int base, bool first2, const double *V0, const double *V1,
+                       hipStream_t st) {
+  const int nt = (int)w->nt, m = nt - base;
+  if (m <= 0) return BA_OK;
+  ProfScope ps(p, PC_LDL_SYRK, st);
+  if (first2) {
+    const int nblk = m + (m > 1 ? m - 1 : 0);
+    hipLaunchKernelGGL(k_ldl_update<2>, dim3(nblk), dim3(256), GEMM_LDS, st, w->S, V0, V1, k, base, nt, nblk);
+  } else {
+    const int nblk = m * (m + 1) / 2;
+    hipLaunchKernelGGL(k_ldl_update<1>, dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_LDS, st, w->S, V0, V1, k, base, nt, nblk);
+  }
+  return BA_OK;
+}
+
+// Two panels per pass over the trailing matrix:
+//   diag(k) trsm(k) | column update of tile column k+1 | diag(k+1) trsm(k+1) | pair update of everything right of k+1.
+// Look-ahead: the pair update is split into the two tile columns the NEXT panels need (side stream, followed by the next
+// diag/trsm/column/diag/trsm chain) and the rest (main stream), so the latency-bound chain hides behind the bulk GEMM.
+// With per-kernel profiling on, everything runs on one stream so that the event pairs time single kernels.
 int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot) {
   const int nt = (int)w->nt;
+  const int64_t panel = (int64_t)nt * NB * NB;
+  double *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
   BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
-  for (int k = 0; k < nt; k++) {
-    {
-      ProfScope ps(p, PC_LDL_DIAG, st);
-      hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(1024), DIAG_LDS, st, w->S + tile_index(k, k) * NB * NB,
-                         w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag);
+  const bool overlap = !p->prof_on && nt > 6;
+  hipStream_t ss = overlap ? w->side : st;
+  if (overlap) {  // the side stream starts after everything already queued on st (S assembly, memset)
+    BA_HIP_CHECK(hipEventRecord(w->ev_bulk, st));
+    BA_HIP_CHECK(hipStreamWaitEvent(ss, w->ev_bulk, 0));
+  }
+  // prologue chain: panels 0 and 1
+  launch_diag(p, w, 0, ss);
+  launch_trsm(p, w, 0, Vs[0][0], ss);
+  if (nt > 1) {
+    launch_col(p, w, 0, Vs[0][0], ss);
+    launch_diag(p, w, 1, ss);
+    launch_trsm(p, w, 1, Vs[0][1], ss);
+  }
+  for (int k = 0, q = 0; k + 2 < nt; k += 2, q ^= 1) {
+    double *V0 = Vs[q][0], *V1 = Vs[q][1], *W0 = Vs[q ^ 1][0], *W1 = Vs[q ^ 1][1];
+    if (overlap) {
+      BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));       // panels k, k+1 factored (and columns k+2.. of the previous pass)
+      BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));
+      if (k > 0) BA_HIP_CHECK(hipStreamWaitEvent(ss, w->ev_bulk, 0));  // previous bulk update finished
     }
-    const int m = nt - k - 1;
-    if (m > 0) {
-      {
-        ProfScope ps(p, PC_LDL_TRSM, st);
-        hipLaunchKernelGGL(k_ldl_trsm, dim3(m), dim3(256), GEMM_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
-                           w->D + (int64_t)k * NB, w->V, k);
-      }
-      {
-        ProfScope ps(p, PC_LDL_SYRK, st);
-        hipLaunchKernelGGL(k_ldl_syrk, dim3(m * (m + 1) / 2), dim3(256), GEMM_LDS, st, w->S, w->V, k);
-      }
+    launch_pair(p, w, k, k + 2, true, V0, V1, ss);   // tile columns k+2, k+3
+    launch_pair(p, w, k, k + 4, false, V0, V1, st);  // the rest
+    if (overlap) BA_HIP_CHECK(hipEventRecord(w->ev_bulk, st));
+    // next chain: panels k+2, k+3
+    launch_diag(p, w, k + 2, ss);
+    launch_trsm(p, w, k + 2, W0, ss);
+    if (k + 3 < nt) {
+      launch_col(p, w, k + 2, W0, ss);
+      launch_diag(p, w, k + 3, ss);
+      launch_trsm(p, w, k + 3, W1, ss);
     }
+  }
+  if (overlap) {
+    BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));
+    BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));
   }
   BA_HIP_CHECK(hipGetLastError());
   if (zero_pivot) {

@@ -60,11 +60,13 @@ struct ProfSlot {
 struct DenseLDL {  // workspace of the blocked LDL^T, n = 9*ncams padded to nt*NB
   int64_t n = 0, nt = 0;
   double *S = nullptr;     // packed lower tiles (may alias the caller's reduce buffer)
-  double *V = nullptr;     // nt tiles: V_i = L_ik * D_k of the current panel
+  double *V = nullptr;     // 4 x nt tiles: V_i = L_ik * D_k of two panel pairs (double-buffered for the look-ahead)
   double *Linv = nullptr;  // nt tiles: inverse of each unit-lower diagonal tile
   double *D = nullptr;     // nt*NB pivots
   int *flag = nullptr;     // device int: set to 1 on an exactly zero pivot
   bool own_S = true;
+  hipStream_t side = nullptr;                       // look-ahead stream of the factorisation
+  hipEvent_t ev_chain = nullptr, ev_bulk = nullptr;
 };
 
 struct ba_problem {
