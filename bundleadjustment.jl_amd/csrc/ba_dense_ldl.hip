@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -159,10 +160,12 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
 // quadrant (w >> 1, w & 1) as 4x4 MFMA blocks (128 accumulator VGPRs).  K is consumed in chunks of KC = 16 staged
 // through one LDS buffer (row stride 18 doubles: conflict-free operand reads); the global loads of chunk c+1 are in
 // flight (registers) while chunk c is multiplied, and two workgroups per CU cover each other's barriers.
-template <int NP>
+// YACC (forward substitution fused into the panel solve): threads 0..127 also accumulate yacc = sum_k B0[tid][k] bk[k]
+// from the B chunks as they pass through LDS.
+template <int NP, bool YACC = false>
 __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double *__restrict__ B0,
                                      const double *__restrict__ A1, const double *__restrict__ B1, double *sA, double *sB,
-                                     d4 acc[4][4]) {
+                                     d4 acc[4][4], const double *__restrict__ bk = nullptr, double *yacc = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
   const int fr = lane & 15, fk = lane >> 4;
@@ -196,6 +199,14 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
         pb[it] = *reinterpret_cast<const d2 *>(B + (lrow + RPS * it) * NB + k0 + 2 * lc2);
       }
     }
+    if (YACC) {
+      if (tid < NB) {
+        double ya = *yacc;
+#pragma unroll
+        for (int q = 0; q < KC; q++) ya += sB[tid * LDK + q] * bk[ch * KC + q];
+        *yacc = ya;
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < KC / 4; kk++) {
       double af[4], bf[4];
@@ -212,10 +223,15 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
 }
 
 // X_i = S_ik * Linv_k'  ->  V_i = X_i,  S_ik = X_i * D_k^-1      (i = k+1+blockIdx.x)
+// FWD: the forward substitution of one right-hand side rides along: y_k = Linv_k b_k (every workgroup, from the B
+// chunks; block 0 stores it) and b_i -= L_ik y_k from the accumulators.
+constexpr size_t TRSM_LDS = GEMM_LDS + (size_t)3 * NB * sizeof(double);
+template <bool FWD>
 __global__ __launch_bounds__(256, 2) void k_ldl_trsm(double *__restrict__ S, const double *__restrict__ Linv_k,
-                                                      const double *__restrict__ D_k, double *__restrict__ V, int k) {
+                                                      const double *__restrict__ D_k, double *__restrict__ V, int k,
+                                                      double *__restrict__ b, double *__restrict__ y) {
   extern __shared__ double lds[];
-  double *sA = lds, *sB = lds + NB * LDK;
+  double *sA = lds, *sB = lds + NB * LDK, *ysh = lds + 2 * NB * LDK, *red = ysh + NB;
   const int i = k + 1 + blockIdx.x;
   double *Sik = S + tile_index(i, k) * NB * NB;
   double *Vi = V + (int64_t)i * NB * NB;
@@ -224,15 +240,29 @@ __global__ __launch_bounds__(256, 2) void k_ldl_trsm(double *__restrict__ S, con
   for (int m = 0; m < 4; m++)
 #pragma unroll
     for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
-  tile_gemm_abt<1>(Sik, Linv_k, nullptr, nullptr, sA, sB, acc);
+  double yacc = 0;
+  tile_gemm_abt<1, FWD>(Sik, Linv_k, nullptr, nullptr, sA, sB, acc, FWD ? b + (int64_t)k * NB : nullptr, &yacc);
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
   const int lane = tid2 & 63, wv = tid2 >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  if (FWD) {
+    if (tid2 < NB) {
+      ysh[tid2] = yacc;
+      if (blockIdx.x == 0) y[(int64_t)k * NB + tid2] = yacc;
+    }
+    __syncthreads();
+  }
+  double part[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) part[m][g] = 0;
 #pragma unroll
   for (int n = 0; n < 4; n++) {
     const int col = wc + 16 * n + (lane & 15);
     const double inv_d = 1.0 / D_k[col];
+    const double wcol = FWD ? ysh[col] * inv_d : 0.0;
 #pragma unroll
     for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -241,7 +271,23 @@ __global__ __launch_bounds__(256, 2) void k_ldl_trsm(double *__restrict__ S, con
         const double xv = acc[m][n][g];
         Vi[row * NB + col] = xv;
         Sik[row * NB + col] = xv * inv_d;
+        if (FWD) part[m][g] += xv * wcol;
       }
+  }
+  if (FWD) {
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        double v = part[m][g];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if ((lane & 15) == 0) red[(wv & 1) * NB + wr + 16 * m + mfma_row(lane, g)] = v;
+      }
+    __syncthreads();
+    if (tid2 < NB) b[(int64_t)i * NB + tid2] -= red[tid2] + red[NB + tid2];
   }
 }
 
@@ -391,8 +437,10 @@ static int set_kernel_attrs() {
   if (g_attr_done) return BA_OK;
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_diag),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_trsm),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_trsm<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSM_LDS));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_trsm<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSM_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1>),
@@ -444,12 +492,22 @@ static int launch_diag(ba_problem *p, DenseLDL *w, int k, hipStream_t st) {
   return BA_OK;
 }
 
-static int launch_trsm(ba_problem *p, DenseLDL *w, int k, double *V, hipStream_t st) {
+// b != null: forward substitution of b fused (y_k and b_i -= L_ik y_k); the last panel has no tile below it, its y_k
+// comes from the stand-alone forward step kernel.
+static int launch_trsm(ba_problem *p, DenseLDL *w, int k, double *V, double *b, hipStream_t st) {
   const int m = (int)w->nt - k - 1;
-  if (m <= 0) return BA_OK;
+  double *y = w->D + w->nt * NB;
+  if (m <= 0) {
+    if (b) hipLaunchKernelGGL(k_fwd_step, dim3(1), dim3(256), 0, st, w->S, w->Linv, b, y, k);
+    return BA_OK;
+  }
   ProfScope ps(p, PC_LDL_TRSM, st);
-  hipLaunchKernelGGL(k_ldl_trsm, dim3(m), dim3(256), GEMM_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
-                     w->D + (int64_t)k * NB, V, k);
+  if (b)
+    hipLaunchKernelGGL(k_ldl_trsm<true>, dim3(m), dim3(256), TRSM_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
+                       w->D + (int64_t)k * NB, V, k, b, y);
+  else
+    hipLaunchKernelGGL(k_ldl_trsm<false>, dim3(m), dim3(256), TRSM_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
+                       w->D + (int64_t)k * NB, V, k, b, y);
   return BA_OK;
 }
 
@@ -482,7 +540,7 @@ static int launch_pair(ba_problem *p, DenseLDL *w, int k, int base, bool first2,
 // Look-ahead: the pair update is split into the two tile columns the NEXT panels need (side stream, followed by the next
 // diag/trsm/column/diag/trsm chain) and the rest (main stream), so the latency-bound chain hides behind the bulk GEMM.
 // With per-kernel profiling on, everything runs on one stream so that the event pairs time single kernels.
-int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot) {
+int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot, double *d_b) {
   const int nt = (int)w->nt;
   const int64_t panel = (int64_t)nt * NB * NB;
   double *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
@@ -495,11 +553,11 @@ int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot
   }
   // prologue chain: panels 0 and 1
   launch_diag(p, w, 0, ss);
-  launch_trsm(p, w, 0, Vs[0][0], ss);
+  launch_trsm(p, w, 0, Vs[0][0], d_b, ss);
   if (nt > 1) {
     launch_col(p, w, 0, Vs[0][0], ss);
     launch_diag(p, w, 1, ss);
-    launch_trsm(p, w, 1, Vs[0][1], ss);
+    launch_trsm(p, w, 1, Vs[0][1], d_b, ss);
   }
   for (int k = 0, q = 0; k + 2 < nt; k += 2, q ^= 1) {
     double *V0 = Vs[q][0], *V1 = Vs[q][1], *W0 = Vs[q ^ 1][0], *W1 = Vs[q ^ 1][1];
@@ -513,11 +571,11 @@ int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot
     if (overlap) BA_HIP_CHECK(hipEventRecord(w->ev_bulk, st));
     // next chain: panels k+2, k+3
     launch_diag(p, w, k + 2, ss);
-    launch_trsm(p, w, k + 2, W0, ss);
+    launch_trsm(p, w, k + 2, W0, d_b, ss);
     if (k + 3 < nt) {
       launch_col(p, w, k + 2, W0, ss);
       launch_diag(p, w, k + 3, ss);
-      launch_trsm(p, w, k + 3, W1, ss);
+      launch_trsm(p, w, k + 3, W1, d_b, ss);
     }
   }
   if (overlap) {
@@ -534,12 +592,13 @@ int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot
   return BA_OK;
 }
 
-int dense_ldl_solve(ba_problem *p, DenseLDL *w, double *d_b, hipStream_t st) {
+int dense_ldl_solve(ba_problem *p, DenseLDL *w, double *d_b, hipStream_t st, bool forward_done) {
   const int nt = (int)w->nt;
   double *y = w->D + (int64_t)nt * NB;
   ProfScope ps(p, PC_SOLVE, st);
-  for (int k = 0; k < nt; k++)
-    hipLaunchKernelGGL(k_fwd_step, dim3(nt - k), dim3(256), 0, st, w->S, w->Linv, d_b, y, k);
+  if (!forward_done)
+    for (int k = 0; k < nt; k++)
+      hipLaunchKernelGGL(k_fwd_step, dim3(nt - k), dim3(256), 0, st, w->S, w->Linv, d_b, y, k);
   for (int k = nt - 1; k >= 0; k--)
     hipLaunchKernelGGL(k_bwd_step, dim3(k + 1), dim3(256), 0, st, w->S, w->Linv, w->D, y, d_b, k);
   BA_HIP_CHECK(hipGetLastError());
@@ -580,9 +639,10 @@ extern "C" int ba_dense_ldl_solve(int device, int64_t n, const double *a_lower_r
   BA_HIP_CHECK(hipEventCreate(&e1));
   int zp = 0;
   BA_HIP_CHECK(hipEventRecord(e0, st));
-  rc = dense_ldl_factor(&tmp, &w, st, nullptr);
+  const bool fused = getenv("BA_LDL_SEPARATE_FORWARD") == nullptr;
+  rc = dense_ldl_factor(&tmp, &w, st, nullptr, fused ? d_b : nullptr);
   BA_HIP_CHECK(hipEventRecord(e1, st));
-  if (rc == BA_OK) rc = dense_ldl_solve(&tmp, &w, d_b, st);
+  if (rc == BA_OK) rc = dense_ldl_solve(&tmp, &w, d_b, st, fused);
   BA_HIP_CHECK(hipMemcpy(&zp, w.flag, sizeof(int), hipMemcpyDeviceToHost));
   BA_HIP_CHECK(hipDeviceSynchronize());
   float ms = 0;

@@ -140,10 +140,12 @@ int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, doubl
 int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S);
 void dense_ldl_free(DenseLDL *w);
 int64_t dense_ldl_tiles_doubles(int64_t n_unpadded);
-// factor S in place (L below the diagonal tiles' diagonal, D separately); *zero_pivot set on exact zero pivot
-int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot);
+// factor S in place (L below the diagonal tiles' diagonal, D separately); *zero_pivot set on exact zero pivot.
+// d_b != null: the forward substitution L y = b of that right-hand side (length nt*NB, clobbered) is fused into the
+// panel solves; pass forward_done = true to dense_ldl_solve afterwards.
+int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot, double *d_b);
 // solve S x = b for one right-hand side held in d_b (length nt*NB, overwritten by x)
-int dense_ldl_solve(ba_problem *p, DenseLDL *w, double *d_b, hipStream_t st);
+int dense_ldl_solve(ba_problem *p, DenseLDL *w, double *d_b, hipStream_t st, bool forward_done);
 
 // ---- LM (ba_lm.hip) ---------------------------------------------------------------------------------
 void lm_free(ba_problem *p);

@@ -249,8 +249,8 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, hipStream_t 
   BA_CHECK(launch_schur_rhs(p, w->J, w->r, w->u, w->rhs, st));
   BA_CHECK(comm_sum(p, w, 0, w->s.off_gc, st));  // S tiles and rhs are adjacent
   int zp = 0;
-  BA_CHECK(dense_ldl_factor(p, &w->ldl, st, nullptr));
-  BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st));
+  BA_CHECK(dense_ldl_factor(p, &w->ldl, st, nullptr, w->rhs));  // forward substitution of rhs rides along
+  BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st, true));
   double *dc = w->delta + 3 * p->npnts;
   BA_HIP_CHECK(hipMemcpyAsync(dc, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
   BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->u, dc, w->delta, st));
