@@ -179,6 +179,7 @@ static int lm_ensure(ba_problem *p) {
   BA_CHECK(dmalloc(&w->gp, 3 * npnts));
   BA_CHECK(dmalloc(&w->Uinv, 6 * npnts));
   BA_CHECK(dmalloc(&w->u, 3 * npnts));
+  BA_CHECK(dmalloc(&w->Yobs, 6 * nobs));
   BA_CHECK(dmalloc(&w->Hcc, 45 * ncams));
   BA_CHECK(dmalloc(&w->partial, (int64_t)RED_BLOCKS));
   BA_CHECK(dmalloc(&w->s.scal_rep, (int64_t)RP_COUNT));
@@ -193,7 +194,7 @@ void lm_free(ba_problem *p) {
   LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
   dense_ldl_free(&w->ldl);
   void *ptrs[] = {w->x, w->x_trial, w->delta, w->r, w->r_trial, w->J, w->Hpp, w->gp, w->Uinv, w->u, w->Hcc,
-                  w->partial, w->colscale, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
+                  w->partial, w->colscale, w->Yobs, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
                   w->tasks.task_a, w->tasks.task_b, w->s.own_red ? w->s.red : nullptr};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
@@ -243,7 +244,7 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, hipStream_t 
   // every rank holds partial Hcc / Schur sums; the lambda I of the camera block is added by rank 0 only
   const double lam_diag = (p->rank == 0) ? lambda : 0.0;
   BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st));
-  BA_CHECK(launch_schur_blocks(p, &w->tasks, w->J, w->Uinv, w->Hcc, lam_diag, w->ldl.S, w->n,
+  BA_CHECK(launch_schur_blocks(p, &w->tasks, w->J, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->n,
                                p->rank == 0 ? w->npad : w->n, st));
   BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
   BA_CHECK(launch_schur_rhs(p, w->J, w->r, w->u, w->rhs, st));

@@ -21,6 +21,7 @@ struct LMWork {
   double *x = nullptr, *x_trial = nullptr, *delta = nullptr;
   double *r = nullptr, *r_trial = nullptr, *J = nullptr;
   double *Hpp = nullptr, *gp = nullptr, *Uinv = nullptr, *u = nullptr;
+  double *Yobs = nullptr;                // 6/obs: U^-1 A_b' of the current damping
   double *Hcc = nullptr, *gc = nullptr;  // gc: 9*ncams
   double *rhs = nullptr;                 // npad
   double *colscale = nullptr;            // nvar (normalize != None)
@@ -33,7 +34,7 @@ struct LMWork {
 
 int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const double *d_gp, double *d_Uinv,
                       double *d_u, hipStream_t st);
-int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv,
+int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
                         const double *d_Hcc, double lambda, double *d_S, int64_t n, int64_t npad, hipStream_t st);
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
                      hipStream_t st);

@@ -157,71 +157,101 @@ __device__ inline void s_store(double *S, int64_t gr, int64_t gc, double v) {
   S[(tile_index(ti, tj) * NB + (gr - ti * NB)) * NB + (gc - tj * NB)] = v;
 }
 
+// Y_b = U_p^-1 A_b'  (3x2, row-major) per observation: the point-side half of Q_ab = A_a Y_b
+__global__ __launch_bounds__(BLK) void k_obs_y(int64_t nobs, const int *__restrict__ pnt0, const double *__restrict__ J,
+                                                const double *__restrict__ Uinv, double *__restrict__ Y) {
+  int64_t o = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (o >= nobs) return;
+  const double *Jo = J + 24 * o, *U = Uinv + 6 * (int64_t)pnt0[o];
+  const double a00 = Jo[0], a01 = Jo[1], a02 = Jo[2], a10 = Jo[12], a11 = Jo[13], a12 = Jo[14];
+  double *y = Y + 6 * o;
+  y[0] = U[0] * a00 + U[1] * a01 + U[2] * a02;
+  y[1] = U[0] * a10 + U[1] * a11 + U[2] * a12;
+  y[2] = U[1] * a00 + U[3] * a01 + U[4] * a02;
+  y[3] = U[1] * a10 + U[3] * a11 + U[4] * a12;
+  y[4] = U[2] * a00 + U[4] * a01 + U[5] * a02;
+  y[5] = U[2] * a10 + U[4] * a11 + U[5] * a12;
+}
+
+// One wave per key.  The sum over the key's tasks of B_a' (Q_ab B_b) is a (9 x 2t)(2t x 9) product: two tasks fill
+// the four k-slots of one v_mfma_f64_16x16x4_f64 (slot = (task, image row alpha)); the A operand is B_a[alpha][i], the
+// B operand G[alpha][j] = Q_ab[alpha][:] B_b[:][j] with Q_ab = A_a Y_b.  Per task one coalesced load of
+// J_a (24), the camera rows of J_b (18) and Y_b (6) is staged in the wave's LDS slot.
+typedef double d4s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *__restrict__ key_ptr,
                                                        const int *__restrict__ key_ca, const int *__restrict__ key_cb,
                                                        const int *__restrict__ task_a, const int *__restrict__ task_b,
-                                                       const int *__restrict__ pnt0, const double *__restrict__ J,
-                                                       const double *__restrict__ Uinv, const double *__restrict__ Hcc,
-                                                       double lambda, double *__restrict__ S) {
-  __shared__ double stage[BLK / 64][2][64];
+                                                       const double *__restrict__ J, const double *__restrict__ Y,
+                                                       const double *__restrict__ Hcc, double lambda,
+                                                       double *__restrict__ S) {
+  __shared__ double stage[BLK / 64][2][48];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t key = (int64_t)blockIdx.x * (BLK / 64) + wv;
   if (key >= nkeys) return;
   const int ca = key_ca[key], cb = key_cb[key];
-  const int e0 = lane, e1 = 64 + lane;
-  const int i0 = e0 / 9, j0 = e0 - 9 * i0;
-  const int i1 = (e1 < 81) ? e1 / 9 : 0, j1 = (e1 < 81) ? e1 - 9 * i1 : 0;
-  double acc0 = 0, acc1 = 0;
+  const int fr = lane & 15, fk = lane >> 4, tl = fk >> 1, al = fk & 1;
   const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
-  int buf = 0;
-  for (int t = t_begin; t < t_end; t++, buf ^= 1) {
-    const int oa = task_a[t], ob = task_b[t];
-    double v = 0;
-    if (lane < 24) v = J[24 * (int64_t)oa + lane];
-    else if (lane < 48) v = J[24 * (int64_t)ob + lane - 24];
-    else if (lane < 54) v = Uinv[6 * (int64_t)pnt0[oa] + lane - 48];
-    double *sg = stage[wv][buf];
-    sg[lane] = v;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double *Ja = sg, *Jb = sg + 24, *Ui = sg + 48;
-    // Y = U^-1 A_b'  (3x2), Q = A_a Y (2x2)
-    double y00 = Ui[0] * Jb[0] + Ui[1] * Jb[1] + Ui[2] * Jb[2];
-    double y10 = Ui[1] * Jb[0] + Ui[3] * Jb[1] + Ui[4] * Jb[2];
-    double y20 = Ui[2] * Jb[0] + Ui[4] * Jb[1] + Ui[5] * Jb[2];
-    double y01 = Ui[0] * Jb[12] + Ui[1] * Jb[13] + Ui[2] * Jb[14];
-    double y11 = Ui[1] * Jb[12] + Ui[3] * Jb[13] + Ui[4] * Jb[14];
-    double y21 = Ui[2] * Jb[12] + Ui[4] * Jb[13] + Ui[5] * Jb[14];
-    double q00 = Ja[0] * y00 + Ja[1] * y10 + Ja[2] * y20;
-    double q01 = Ja[0] * y01 + Ja[1] * y11 + Ja[2] * y21;
-    double q10 = Ja[12] * y00 + Ja[13] * y10 + Ja[14] * y20;
-    double q11 = Ja[12] * y01 + Ja[13] * y11 + Ja[14] * y21;
-    {
-      double ba0 = Ja[3 + i0], ba1 = Ja[15 + i0], bb0 = Jb[3 + j0], bb1 = Jb[15 + j0];
-      acc0 += (ba0 * q00 + ba1 * q10) * bb0 + (ba0 * q01 + ba1 * q11) * bb1;
+  // element `lane` (< 48) of a task record: J_a[0..23] | J_b camera rows (2 x 9) | Y_b[0..5]
+  const int e = lane;
+  const int eoff = e < 24 ? e : (e < 33 ? e - 24 + 3 : (e < 42 ? e - 33 + 15 : e - 42));
+  d4s acc = {0, 0, 0, 0};
+  // Latency hiding inside one wave: task indices come 64 at a time with one coalesced load and are handed out with
+  // v_readlane; the records of the next two task pairs are in flight (registers) while the current pair is multiplied.
+  for (int c0t = t_begin; c0t < t_end; c0t += 64) {
+    const int nin = (t_end - c0t) < 64 ? (t_end - c0t) : 64;
+    int my_oa = 0, my_ob = 0;
+    if (lane < nin) {
+      my_oa = task_a[c0t + lane];
+      my_ob = task_b[c0t + lane];
     }
-    {
-      double ba0 = Ja[3 + i1], ba1 = Ja[15 + i1], bb0 = Jb[3 + j1], bb1 = Jb[15 + j1];
-      acc1 += (ba0 * q00 + ba1 * q10) * bb0 + (ba0 * q01 + ba1 * q11) * bb1;
+    auto fetch = [&](int tq) -> double {  // element e of task tq of this chunk (0 when out of range; tq is wave-uniform)
+      if (tq >= nin) return 0.0;
+      const int oa = __builtin_amdgcn_readlane(my_oa, tq), ob = __builtin_amdgcn_readlane(my_ob, tq);
+      if (e < 24) return J[24 * (int64_t)oa + eoff];
+      if (e < 42) return J[24 * (int64_t)ob + eoff];
+      if (e < 48) return Y[6 * (int64_t)ob + eoff];
+      return 0.0;
+    };
+    double p0a = fetch(0), p0b = fetch(1), p1a = fetch(2), p1b = fetch(3);
+    for (int tp = 0; tp < nin; tp += 2) {
+      const double ca_v = p0a, cb_v = p0b;
+      p0a = p1a;
+      p0b = p1b;
+      p1a = fetch(tp + 4);
+      p1b = fetch(tp + 5);
+      if (e < 48) {
+        stage[wv][0][e] = ca_v;
+        stage[wv][1][e] = cb_v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double *sg = stage[wv][tl];
+      const bool on = (fr < 9) && (tp + tl < nin);
+      const int fi = fr < 9 ? fr : 0;
+      const double a0 = sg[12 * al], a1 = sg[12 * al + 1], a2 = sg[12 * al + 2];
+      const double q0 = a0 * sg[42] + a1 * sg[44] + a2 * sg[46];
+      const double q1 = a0 * sg[43] + a1 * sg[45] + a2 * sg[47];
+      const double aop = on ? sg[12 * al + 3 + fi] : 0.0;
+      const double bop = on ? q0 * sg[24 + fi] + q1 * sg[33 + fi] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
     }
   }
   const int64_t r0 = 9 * (int64_t)ca, c0 = 9 * (int64_t)cb;
-  {
-    double v = -acc0;
-    if (ca == cb) {
-      int hi = i0 > j0 ? i0 : j0, lo = i0 > j0 ? j0 : i0;
-      v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i0 == j0 ? lambda : 0.0);
+  if (fr < 9) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int i = fk + 4 * g, j = fr;
+      if (i < 9) {
+        double v = -acc[g];
+        if (ca == cb) {
+          int hi = i > j ? i : j, lo = i > j ? j : i;
+          v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i == j ? lambda : 0.0);
+        }
+        if (r0 + i >= c0 + j) s_store(S, r0 + i, c0 + j, v);
+      }
     }
-    if (r0 + i0 >= c0 + j0) s_store(S, r0 + i0, c0 + j0, v);
-  }
-  if (e1 < 81) {
-    double v = -acc1;
-    if (ca == cb) {
-      int hi = i1 > j1 ? i1 : j1, lo = i1 > j1 ? j1 : i1;
-      v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i1 == j1 ? lambda : 0.0);
-    }
-    if (r0 + i1 >= c0 + j1) s_store(S, r0 + i1, c0 + j1, v);
   }
 }
 
@@ -369,13 +399,15 @@ int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const d
   return BA_OK;
 }
 
-int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv,
+int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
                         const double *d_Hcc, double lambda, double *d_S, int64_t n, int64_t npad, hipStream_t st) {
   ProfScope ps(p, PC_SCHUR_S, st);
   BA_HIP_CHECK(hipMemsetAsync(d_S, 0, (size_t)dense_ldl_tiles_doubles(n) * sizeof(double), st));
+  if (p->nobs > 0)
+    hipLaunchKernelGGL(k_obs_y, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->pnt0, d_J, d_Uinv, d_Y);
   if (T->nkeys > 0)
     hipLaunchKernelGGL(k_schur_blocks, dim3(grid_for(T->nkeys, BLK / 64)), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
-                       T->key_ca, T->key_cb, T->task_a, T->task_b, p->pnt0, d_J, d_Uinv, d_Hcc, lambda, d_S);
+                       T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_S);
   if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
