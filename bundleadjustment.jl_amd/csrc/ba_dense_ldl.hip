@@ -24,7 +24,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int KC = 16;       // K chunk of the GEMM kernels staged through LDS
 constexpr int LDK = KC + 2;  // row stride 36 dwords: 36i+2k hit distinct banks for the MFMA operand reads
-constexpr size_t GEMM_LDS = (size_t)2 * NB * LDK * sizeof(double);
+constexpr size_t GEMM_LDS = (size_t)2 * 2 * NB * LDK * sizeof(double);  // two (A | B) chunk buffers
 
 // v_mfma_f64_16x16x4_f64 C/D layout: lane l, result register g hold C[row][l & 15]
 __device__ inline int mfma_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
@@ -40,21 +40,43 @@ constexpr int XDL = 18;
 constexpr size_t DIAG_LDS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB) * sizeof(double);
 
 __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, double *__restrict__ Linv_k,
-                                                   double *__restrict__ D_k, int *__restrict__ flag) {
+                                                   double *__restrict__ D_k, int *__restrict__ flag,
+                                                   unsigned long long *__restrict__ stamps) {
   extern __shared__ double sm[];
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;  // diagnostic phase timers (stamps != null only)
+#define STAMP(slot)                                        \
+  if (stamps) {                                            \
+    unsigned long long tnow = __builtin_amdgcn_s_memtime(); \
+    tacc[slot] += tnow - tlast;                            \
+    tlast = tnow;                                          \
+  }
+  if (stamps) tlast = __builtin_amdgcn_s_memtime();
   double *a = sm, *xd = sm + NB * LDA2, *dd = xd + 8 * 16 * XDL, *dinv = dd + NB;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    int i = idx >> 7, j = idx & (NB - 1);
-    a[i * LDA2 + j] = (j <= i) ? Skk[idx] : 0.0;
+  // tile -> LDS: 16-byte loads, 8 in flight per thread; the strict upper triangle is zeroed
+#pragma unroll
+  for (int b0 = 0; b0 < 4; b0++) {
+    d2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const d2 *>(Skk + 2 * ((b0 * 8 + q) * 256 + tid));
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int idx = 2 * ((b0 * 8 + q) * 256 + tid), i = idx >> 7, j = idx & (NB - 1);
+      d2 w = v[q];
+      if (j > i) w[0] = 0.0;
+      if (j + 1 > i) w[1] = 0.0;
+      *reinterpret_cast<d2 *>(a + i * LDA2 + j) = w;
+    }
   }
   for (int idx = tid; idx < 8 * 16 * XDL; idx += 256) xd[idx] = 0.0;
   __syncthreads();
+  STAMP(0)
   for (int jb = 0; jb < 8; jb++) {
     const int o = 16 * jb;
     double *xj = xd + jb * 16 * XDL;
-    {  // unblocked LDL' of the diagonal block, one element per thread
+    {  // unblocked LDL' of the diagonal block, one element per thread (a single-wave variant without the 16
+       // workgroup barriers measured 40 us SLOWER per tile: the LDS round trips of one wave serialise)
       const int i = tid >> 4, c = tid & 15;
       for (int j = 0; j < 16; j++) {
         const double d = a[(o + j) * LDA2 + o + j];
@@ -68,6 +90,7 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
         __syncthreads();
       }
     }
+    STAMP(1)
     if (tid < 16) {  // column tid of the inverse of the unit-lower block, l[i][m] = a[i][m] * dinv[m]
       const int c = tid;
       double y[16];  // y[m] = dinv[m] * x[m]
@@ -82,6 +105,7 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
       }
     }
     __syncthreads();
+    STAMP(2)
     // X(I) = A(I,jb) * Linv16'
     for (int I = jb + 1 + wv; I < 8; I += 4) {
       d4 acc = {0, 0, 0, 0};
@@ -113,6 +137,7 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
       for (int g = 0; g < 4; g++) a[(16 * I + mfma_row(lane, g)) * LDA2 + 16 * J + fr] = acc[g];
     }
     __syncthreads();
+    STAMP(3)
   }
   // full inverse: X(I,J) = -Linv16(I) * sum_{K=J}^{I-1} L(I,K) X(K,J); X(I,J)[i][j] kept at a[16J+j][16I+i]
   for (int I = 1; I < 8; I++) {
@@ -136,30 +161,43 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
     }
     __syncthreads();
   }
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int i = idx >> 7, c = idx & (NB - 1);
-    double l, x;
-    if (c < i) {
-      l = a[i * LDA2 + c] * dinv[c];
-      x = ((i >> 4) == (c >> 4)) ? xd[((i >> 4) * 16 + (i & 15)) * XDL + (c & 15)] : a[c * LDA2 + i];
-    } else if (c == i) {
-      l = dd[i];  // D on the diagonal of the stored tile (informative only)
-      x = 1.0;
-    } else {
-      l = 0.0;
-      x = 0.0;
+  STAMP(4)
+  for (int it = 0; it < 32; it++) {  // LDS -> L (scaled, D on the diagonal) and Linv tiles, 16-byte stores
+    const int idx = 2 * (it * 256 + tid), i = idx >> 7, c0 = idx & (NB - 1);
+    d2 lv, xv;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const int c = c0 + e;
+      double l, x;
+      if (c < i) {
+        l = a[i * LDA2 + c] * dinv[c];
+        x = ((i >> 4) == (c >> 4)) ? xd[((i >> 4) * 16 + (i & 15)) * XDL + (c & 15)] : a[c * LDA2 + i];
+      } else if (c == i) {
+        l = dd[i];  // D on the diagonal of the stored tile (informative only)
+        x = 1.0;
+      } else {
+        l = 0.0;
+        x = 0.0;
+      }
+      lv[e] = l;
+      xv[e] = x;
     }
-    Skk[idx] = l;
-    Linv_k[idx] = x;
+    *reinterpret_cast<d2 *>(Skk + idx) = lv;
+    *reinterpret_cast<d2 *>(Linv_k + idx) = xv;
   }
   if (tid < NB) D_k[tid] = dd[tid];
+  STAMP(5)
+  if (stamps && tid == 0)
+    for (int q = 0; q < 6; q++) stamps[q] = tacc[q];
+#undef STAMP
 }
 
 // ---- 128 x 128 x (128 NP) tile product C = sum_p A_p * B_p' on the matrix cores ------------------------------------
 // A_p, B_p: contiguous row-major 128x128 tiles in global memory.  256 threads = 4 waves, wave w owns the 64x64
 // quadrant (w >> 1, w & 1) as 4x4 MFMA blocks (128 accumulator VGPRs).  K is consumed in chunks of KC = 16 staged
-// through one LDS buffer (row stride 18 doubles: conflict-free operand reads); the global loads of chunk c+1 are in
-// flight (registers) while chunk c is multiplied, and two workgroups per CU cover each other's barriers.
+// through two LDS buffers (row stride 18 doubles: conflict-free operand reads), one barrier per chunk: while chunk c is
+// multiplied, chunk c+1 moves registers -> other buffer and the global loads of chunk c+2 are in flight; two
+// workgroups per CU cover each other's barriers.
 // YACC (forward substitution fused into the panel solve): threads 0..127 also accumulate yacc = sum_k B0[tid][k] bk[k]
 // from the B chunks as they pass through LDS.
 template <int NP, bool YACC = false>
@@ -180,16 +218,34 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
     pb[it] = *reinterpret_cast<const d2 *>(B0 + (lrow + RPS * it) * NB + 2 * lc2);
   }
   constexpr int NCH = NP * (NB / KC);
-  for (int ch = 0; ch < NCH; ch++) {
-    __syncthreads();
+  constexpr int BUF = 2 * NB * LDK;  // doubles per LDS buffer (A | B); two buffers: sA/sB point at buffer 0
+  // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
+#pragma unroll
+  for (int it = 0; it < NLD; it++) {
+    *reinterpret_cast<d2 *>(sA + (lrow + RPS * it) * LDK + 2 * lc2) = pa[it];
+    *reinterpret_cast<d2 *>(sB + (lrow + RPS * it) * LDK + 2 * lc2) = pb[it];
+  }
+  if (NCH > 1) {
 #pragma unroll
     for (int it = 0; it < NLD; it++) {
-      *reinterpret_cast<d2 *>(sA + (lrow + RPS * it) * LDK + 2 * lc2) = pa[it];
-      *reinterpret_cast<d2 *>(sB + (lrow + RPS * it) * LDK + 2 * lc2) = pb[it];
+      pa[it] = *reinterpret_cast<const d2 *>(A0 + (lrow + RPS * it) * NB + KC + 2 * lc2);
+      pb[it] = *reinterpret_cast<const d2 *>(B0 + (lrow + RPS * it) * NB + KC + 2 * lc2);
     }
+  }
+  for (int ch = 0; ch < NCH; ch++) {
+    // one barrier per chunk: buffer ch&1 is complete, and everybody has finished reading the other buffer
     __syncthreads();
-    if (ch + 1 < NCH) {
-      const int nx = ch + 1;
+    double *cA = sA + (ch & 1) * BUF, *cB = sB + (ch & 1) * BUF;
+    if (ch + 1 < NCH) {  // chunk ch+1 (registers) -> other buffer; these stores overlap the MFMAs below
+      double *nA = sA + ((ch + 1) & 1) * BUF, *nB = sB + ((ch + 1) & 1) * BUF;
+#pragma unroll
+      for (int it = 0; it < NLD; it++) {
+        *reinterpret_cast<d2 *>(nA + (lrow + RPS * it) * LDK + 2 * lc2) = pa[it];
+        *reinterpret_cast<d2 *>(nB + (lrow + RPS * it) * LDK + 2 * lc2) = pb[it];
+      }
+    }
+    if (ch + 2 < NCH) {  // chunk ch+2 -> registers (in flight during this chunk and the next barrier)
+      const int nx = ch + 2;
       const double *A = (NP == 2 && nx >= NB / KC) ? A1 : A0;
       const double *B = (NP == 2 && nx >= NB / KC) ? B1 : B0;
       const int k0 = (nx & (NB / KC - 1)) * KC;
@@ -203,7 +259,7 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
       if (tid < NB) {
         double ya = *yacc;
 #pragma unroll
-        for (int q = 0; q < KC; q++) ya += sB[tid * LDK + q] * bk[ch * KC + q];
+        for (int q = 0; q < KC; q++) ya += cB[tid * LDK + q] * bk[ch * KC + q];
         *yacc = ya;
       }
     }
@@ -211,9 +267,9 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
     for (int kk = 0; kk < KC / 4; kk++) {
       double af[4], bf[4];
 #pragma unroll
-      for (int m = 0; m < 4; m++) af[m] = sA[(wr + 16 * m + fr) * LDK + kk * 4 + fk];
+      for (int m = 0; m < 4; m++) af[m] = cA[(wr + 16 * m + fr) * LDK + kk * 4 + fk];
 #pragma unroll
-      for (int n = 0; n < 4; n++) bf[n] = sB[(wc + 16 * n + fr) * LDK + kk * 4 + fk];
+      for (int n = 0; n < 4; n++) bf[n] = cB[(wc + 16 * n + fr) * LDK + kk * 4 + fk];
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -231,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void k_ldl_trsm(double *__restrict__ S, con
                                                       const double *__restrict__ D_k, double *__restrict__ V, int k,
                                                       double *__restrict__ b, double *__restrict__ y) {
   extern __shared__ double lds[];
-  double *sA = lds, *sB = lds + NB * LDK, *ysh = lds + 2 * NB * LDK, *red = ysh + NB;
+  double *sA = lds, *sB = lds + NB * LDK, *ysh = lds + 4 * NB * LDK, *red = ysh + NB;
   const int i = k + 1 + blockIdx.x;
   double *Sik = S + tile_index(i, k) * NB * NB;
   double *Vi = V + (int64_t)i * NB * NB;
@@ -295,7 +351,9 @@ __global__ __launch_bounds__(256, 2) void k_ldl_trsm(double *__restrict__ S, con
 // MODE 1 (pair):  S_ij -= V0_i L_jk' + V1_i L_{j,k+1}'  for the lower-triangular tile pairs base <= j <= i (K = 256): the
 // trailing matrix is read and written once per TWO panels, which halves its HBM traffic per flop.
 // MODE 2 (pair, the two tile columns base and base+1 only): what the next two panels need first (look-ahead).
-template <int MODE>
+// DBG (micro-benchmark only, ba_debug_update_bench): bit 0 = store instead of read-modify-write, bit 1 = every
+// workgroup reads the same operand tiles (L2-resident operands).
+template <int MODE, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, const double *__restrict__ V0,
                                                         const double *__restrict__ V1, int k, int base, int nt,
                                                         int nblk) {
@@ -334,25 +392,38 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, c
   for (int m = 0; m < 4; m++)
 #pragma unroll
     for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  const int io = (DBG & 2) ? base : i, jo = (DBG & 2) ? base : j;
   if (MODE == 0)
-    tile_gemm_abt<1>(V0 + (int64_t)i * NB * NB, S + tile_index(j, k) * NB * NB, nullptr, nullptr, sA, sB, acc);
+    tile_gemm_abt<1>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, nullptr, nullptr, sA, sB, acc);
   else
-    tile_gemm_abt<2>(V0 + (int64_t)i * NB * NB, S + tile_index(j, k) * NB * NB, V1 + (int64_t)i * NB * NB,
-                     S + tile_index(j, k + 1) * NB * NB, sA, sB, acc);
+    tile_gemm_abt<2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                     S + tile_index(jo, k + 1) * NB * NB, sA, sB, acc);
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
   const int lane = tid2 & 63, wv = tid2 >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  // epilogue: the 64 values of a lane are read-modify-written in two batches of 32 so that 32 loads are in flight at once
+  double *cbase = Sij + (wr + (lane >> 4)) * NB + wc + (lane & 15);
 #pragma unroll
-  for (int n = 0; n < 4; n++) {
-    const int col = wc + 16 * n + (lane & 15);
+  for (int h = 0; h < 2; h++) {
+    double cv[2][4][4];
+    if (!(DBG & 1)) {
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+      for (int n2 = 0; n2 < 2; n2++)
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int row = wr + 16 * m + mfma_row(lane, g);
-        Sij[row * NB + col] -= acc[m][n][g];
-      }
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) cv[n2][m][g] = cbase[(16 * m + 4 * g) * NB + 16 * (2 * h + n2)];
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < 2; n2++)
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const double a = acc[m][2 * h + n2][g];
+          cbase[(16 * m + 4 * g) * NB + 16 * (2 * h + n2)] = (DBG & 1) ? a : cv[n2][m][g] - a;
+        }
   }
 }
 
@@ -447,6 +518,12 @@ static int set_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 3>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
   g_attr_done = true;
   return BA_OK;
 }
@@ -464,7 +541,35 @@ int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S) {
     w->own_S = true;
   }
   BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(double)));  // 2 x two panels of L*D
-  BA_HIP_CHECK(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
+  {
+    // Look-ahead needs the latency-bound panel chain to run BESIDE the bulk update, but the bulk GEMM fills every
+    // CU's register file, so the chain's workgroups would queue behind it.  Give each its own CUs: the side stream gets
+    // `side_cus` CUs (spread over the XCDs by taking every (256/side_cus)-th bit), the bulk stream the rest.
+    int side_cus = 32;
+    if (const char *e = getenv("BA_LDL_SIDE_CUS")) side_cus = atoi(e);
+    hipDeviceProp_t prop;
+    int dev = 0;
+    BA_HIP_CHECK(hipGetDevice(&dev));
+    BA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    const int ncu = prop.multiProcessorCount;
+    w->side_cus = 0;
+    if (side_cus > 0 && side_cus < ncu && ncu <= 1024) {
+      uint32_t m_side[32] = {0}, m_bulk[32] = {0};
+      const int stride = ncu / side_cus;
+      int cnt = 0;
+      for (int c = 0; c < ncu; c++) {
+        const bool s_ = (c % stride == 0) && cnt < side_cus;
+        if (s_) cnt++;
+        (s_ ? m_side : m_bulk)[c / 32] |= 1u << (c % 32);
+      }
+      const uint32_t words = (uint32_t)((ncu + 31) / 32);
+      if (hipExtStreamCreateWithCUMask(&w->side, words, m_side) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&w->bulk, words, m_bulk) == hipSuccess)
+        w->side_cus = cnt;
+      else
+        (void)hipGetLastError();
+    }
+  }
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_chain, hipEventDisableTiming));
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_bulk, hipEventDisableTiming));
   BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(double)));
@@ -480,6 +585,7 @@ void dense_ldl_free(DenseLDL *w) {
   if (w->D) (void)hipFree(w->D);
   if (w->flag) (void)hipFree(w->flag);
   if (w->side) (void)hipStreamDestroy(w->side);
+  if (w->bulk) (void)hipStreamDestroy(w->bulk);
   if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
   if (w->ev_bulk) (void)hipEventDestroy(w->ev_bulk);
   *w = DenseLDL();
@@ -488,7 +594,7 @@ void dense_ldl_free(DenseLDL *w) {
 static int launch_diag(ba_problem *p, DenseLDL *w, int k, hipStream_t st) {
   ProfScope ps(p, PC_LDL_DIAG, st);
   hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), DIAG_LDS, st, w->S + tile_index(k, k) * NB * NB,
-                     w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag);
+                     w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag, (unsigned long long *)nullptr);
   return BA_OK;
 }
 
@@ -545,12 +651,18 @@ int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot
   const int64_t panel = (int64_t)nt * NB * NB;
   double *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
   BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
-  const bool overlap = !p->prof_on && nt > 6;
-  hipStream_t ss = overlap ? w->side : st;
-  if (overlap) {  // the side stream starts after everything already queued on st (S assembly, memset)
+  // pairs whose bulk update is shorter than the panel chain gain nothing from giving CUs away: overlap only while
+  // at least OVERLAP_MIN_TILES tile rows remain
+  constexpr int OVERLAP_MIN_TILES = 48;
+  const bool can_overlap = !p->prof_on && w->side_cus > 0 && nt > OVERLAP_MIN_TILES;
+  hipStream_t ss = can_overlap ? w->side : st;  // panel chain
+  hipStream_t sb = can_overlap ? w->bulk : st;  // bulk trailing updates
+  if (can_overlap) {  // fork: both streams start after everything already queued on st (S assembly, memset)
     BA_HIP_CHECK(hipEventRecord(w->ev_bulk, st));
     BA_HIP_CHECK(hipStreamWaitEvent(ss, w->ev_bulk, 0));
+    BA_HIP_CHECK(hipStreamWaitEvent(sb, w->ev_bulk, 0));
   }
+  bool forked = can_overlap;
   // prologue chain: panels 0 and 1
   launch_diag(p, w, 0, ss);
   launch_trsm(p, w, 0, Vs[0][0], d_b, ss);
@@ -561,14 +673,22 @@ int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot
   }
   for (int k = 0, q = 0; k + 2 < nt; k += 2, q ^= 1) {
     double *V0 = Vs[q][0], *V1 = Vs[q][1], *W0 = Vs[q ^ 1][0], *W1 = Vs[q ^ 1][1];
-    if (overlap) {
-      BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));       // panels k, k+1 factored (and columns k+2.. of the previous pass)
+    if (forked && nt - k - 2 < OVERLAP_MIN_TILES) {  // join: the tail runs on the whole GPU, one stream
+      BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));
       BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));
+      BA_HIP_CHECK(hipEventRecord(w->ev_bulk, sb));
+      BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_bulk, 0));
+      ss = sb = st;
+      forked = false;
+    }
+    if (forked) {
+      BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));  // panels k, k+1 factored
+      BA_HIP_CHECK(hipStreamWaitEvent(sb, w->ev_chain, 0));
       if (k > 0) BA_HIP_CHECK(hipStreamWaitEvent(ss, w->ev_bulk, 0));  // previous bulk update finished
     }
-    launch_pair(p, w, k, k + 2, true, V0, V1, ss);   // tile columns k+2, k+3
-    launch_pair(p, w, k, k + 4, false, V0, V1, st);  // the rest
-    if (overlap) BA_HIP_CHECK(hipEventRecord(w->ev_bulk, st));
+    launch_pair(p, w, k, k + 2, true, V0, V1, ss);   // tile columns k+2, k+3: what the next panels need
+    launch_pair(p, w, k, k + 4, false, V0, V1, sb);  // the rest
+    if (forked) BA_HIP_CHECK(hipEventRecord(w->ev_bulk, sb));
     // next chain: panels k+2, k+3
     launch_diag(p, w, k + 2, ss);
     launch_trsm(p, w, k + 2, W0, d_b, ss);
@@ -578,9 +698,11 @@ int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot
       launch_trsm(p, w, k + 3, W1, d_b, ss);
     }
   }
-  if (overlap) {
+  if (forked) {
     BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));
     BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));
+    BA_HIP_CHECK(hipEventRecord(w->ev_bulk, sb));
+    BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_bulk, 0));
   }
   BA_HIP_CHECK(hipGetLastError());
   if (zero_pivot) {
@@ -660,4 +782,79 @@ extern "C" int ba_dense_ldl_solve(int device, int64_t n, const double *a_lower_r
     return BA_ERR_ZERO_PIVOT;
   }
   return rc;
+}
+
+// micro-benchmark of the bulk trailing update (tools/bench_update.py): one pair update of an nt x nt tile matrix
+extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_out) {
+  BA_CHECK(set_kernel_attrs());
+  const size_t tiles = (size_t)nt * (nt + 1) / 2 * NB * NB;
+  double *S = nullptr, *V = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&S, tiles * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&V, (size_t)2 * nt * NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMemset(S, 0, tiles * sizeof(double)));
+  BA_HIP_CHECK(hipMemset(V, 0, (size_t)2 * nt * NB * NB * sizeof(double)));
+  const int m = nt - 2, nblk = m * (m + 1) / 2, grid = ((nblk + 7) / 8) * 8;
+  hipEvent_t e0, e1;
+  BA_HIP_CHECK(hipEventCreate(&e0));
+  BA_HIP_CHECK(hipEventCreate(&e1));
+  auto launch = [&]() {
+    const double *V0 = V, *V1 = V + (size_t)nt * NB * NB;
+    switch (variant) {
+      case 1: hipLaunchKernelGGL((k_ldl_update<1, 1>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
+      case 2: hipLaunchKernelGGL((k_ldl_update<1, 2>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
+      case 3: hipLaunchKernelGGL((k_ldl_update<1, 3>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
+      default: hipLaunchKernelGGL((k_ldl_update<1, 0>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk);
+    }
+  };
+  {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_ldl_update<1, 0>), 256, GEMM_LDS);
+    if (variant == 0) fprintf(stderr, "[debug] update<1>: occupancy API says %d workgroups/CU at %zu B LDS\n", nb, GEMM_LDS);
+  }
+  launch();
+  BA_HIP_CHECK(hipDeviceSynchronize());
+  BA_HIP_CHECK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; r++) launch();
+  BA_HIP_CHECK(hipEventRecord(e1, 0));
+  BA_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / reps;
+  (void)hipFree(S);
+  (void)hipFree(V);
+  return BA_OK;
+}
+
+// diagnostic: phase cycle counts of the diagonal-tile kernel (load, pivots, inverse16, trsm16+syrk16, full inverse, store)
+extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
+  BA_CHECK(set_kernel_attrs());
+  double *S = nullptr, *Li = nullptr, *D = nullptr;
+  int *flag = nullptr;
+  unsigned long long *st = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&S, NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&Li, NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&D, NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&flag, sizeof(int)));
+  BA_HIP_CHECK(hipMalloc((void **)&st, 6 * sizeof(unsigned long long)));
+  std::vector<double> h((size_t)NB * NB, 0.0);
+  for (int i = 0; i < NB; i++)
+    for (int j = 0; j <= i; j++) h[(size_t)i * NB + j] = (i == j) ? 300.0 + i : 1.0 / (1 + i + j);
+  hipEvent_t e0, e1;
+  BA_HIP_CHECK(hipEventCreate(&e0));
+  BA_HIP_CHECK(hipEventCreate(&e1));
+  float ms = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    BA_HIP_CHECK(hipMemcpy(S, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    BA_HIP_CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), DIAG_LDS, 0, S, Li, D, flag, rep == 2 ? st : nullptr);
+    BA_HIP_CHECK(hipEventRecord(e1, 0));
+    BA_HIP_CHECK(hipEventSynchronize(e1));
+    if (rep == 1) BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  unsigned long long hs[6];
+  BA_HIP_CHECK(hipMemcpy(hs, st, sizeof hs, hipMemcpyDeviceToHost));
+  for (int q = 0; q < 6; q++) cycles6[q] = (double)hs[q];
+  *ms_out = ms;
+  (void)hipFree(S); (void)hipFree(Li); (void)hipFree(D); (void)hipFree(flag); (void)hipFree(st);
+  return BA_OK;
 }

@@ -65,7 +65,8 @@ struct DenseLDL {  // workspace of the blocked LDL^T, n = 9*ncams padded to nt*N
   double *D = nullptr;     // nt*NB pivots
   int *flag = nullptr;     // device int: set to 1 on an exactly zero pivot
   bool own_S = true;
-  hipStream_t side = nullptr;                       // look-ahead stream of the factorisation
+  hipStream_t side = nullptr, bulk = nullptr;      // look-ahead: panel chain / bulk update streams (disjoint CU masks)
+  int side_cus = 0;                                 // 0: no CU-masked streams, factorisation runs on one stream
   hipEvent_t ev_chain = nullptr, ev_bulk = nullptr;
 };
 
