@@ -24,7 +24,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int KC = 16;       // K chunk of the GEMM kernels staged through LDS
 constexpr int LDK = KC + 2;  // row stride 36 dwords: 36i+2k hit distinct banks for the MFMA operand reads
-constexpr size_t GEMM_LDS = (size_t)2 * 2 * NB * LDK * sizeof(double);  // two (A | B) chunk buffers
+constexpr int DBUF = 0;  // 1: two LDS chunk buffers + one barrier per chunk; 0: one buffer + two barriers (measured faster:
+                         // 54.4 vs 52.3 TFLOP/s on the pair update, the barrier is not the limiter and 2x LDS costs occupancy slack)
+constexpr size_t GEMM_LDS = (size_t)(DBUF ? 2 : 1) * 2 * NB * LDK * sizeof(double);
 
 // v_mfma_f64_16x16x4_f64 C/D layout: lane l, result register g hold C[row][l & 15]
 __device__ inline int mfma_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
@@ -218,25 +220,27 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
     pb[it] = *reinterpret_cast<const d2 *>(B0 + (lrow + RPS * it) * NB + 2 * lc2);
   }
   constexpr int NCH = NP * (NB / KC);
-  constexpr int BUF = 2 * NB * LDK;  // doubles per LDS buffer (A | B); two buffers: sA/sB point at buffer 0
-  // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
-#pragma unroll
-  for (int it = 0; it < NLD; it++) {
-    *reinterpret_cast<d2 *>(sA + (lrow + RPS * it) * LDK + 2 * lc2) = pa[it];
-    *reinterpret_cast<d2 *>(sB + (lrow + RPS * it) * LDK + 2 * lc2) = pb[it];
-  }
-  if (NCH > 1) {
+  constexpr int BUF = DBUF ? 2 * NB * LDK : 0;  // doubles per LDS buffer (A | B); sA/sB point at buffer 0
+  if (DBUF) {  // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
 #pragma unroll
     for (int it = 0; it < NLD; it++) {
-      pa[it] = *reinterpret_cast<const d2 *>(A0 + (lrow + RPS * it) * NB + KC + 2 * lc2);
-      pb[it] = *reinterpret_cast<const d2 *>(B0 + (lrow + RPS * it) * NB + KC + 2 * lc2);
+      *reinterpret_cast<d2 *>(sA + (lrow + RPS * it) * LDK + 2 * lc2) = pa[it];
+      *reinterpret_cast<d2 *>(sB + (lrow + RPS * it) * LDK + 2 * lc2) = pb[it];
+    }
+    if (NCH > 1) {
+#pragma unroll
+      for (int it = 0; it < NLD; it++) {
+        pa[it] = *reinterpret_cast<const d2 *>(A0 + (lrow + RPS * it) * NB + KC + 2 * lc2);
+        pb[it] = *reinterpret_cast<const d2 *>(B0 + (lrow + RPS * it) * NB + KC + 2 * lc2);
+      }
     }
   }
   for (int ch = 0; ch < NCH; ch++) {
-    // one barrier per chunk: buffer ch&1 is complete, and everybody has finished reading the other buffer
+    // DBUF: buffer ch&1 is complete and everybody has finished reading the other one.  Single buffer: everybody has
+    // finished reading the previous chunk.
     __syncthreads();
     double *cA = sA + (ch & 1) * BUF, *cB = sB + (ch & 1) * BUF;
-    if (ch + 1 < NCH) {  // chunk ch+1 (registers) -> other buffer; these stores overlap the MFMAs below
+    if (DBUF ? (ch + 1 < NCH) : true) {  // registers -> LDS (DBUF: chunk ch+1 into the other buffer, overlapping the MFMAs)
       double *nA = sA + ((ch + 1) & 1) * BUF, *nB = sB + ((ch + 1) & 1) * BUF;
 #pragma unroll
       for (int it = 0; it < NLD; it++) {
@@ -244,8 +248,9 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
         *reinterpret_cast<d2 *>(nB + (lrow + RPS * it) * LDK + 2 * lc2) = pb[it];
       }
     }
-    if (ch + 2 < NCH) {  // chunk ch+2 -> registers (in flight during this chunk and the next barrier)
-      const int nx = ch + 2;
+    if (!DBUF) __syncthreads();
+    const int nx = ch + (DBUF ? 2 : 1);
+    if (nx < NCH) {  // next chunk -> registers, in flight while this chunk is multiplied
       const double *A = (NP == 2 && nx >= NB / KC) ? A1 : A0;
       const double *B = (NP == 2 && nx >= NB / KC) ? B1 : B0;
       const int k0 = (nx & (NB / KC - 1)) * KC;
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_ldl_trsm(double *__restrict__ S, con
                                                       const double *__restrict__ D_k, double *__restrict__ V, int k,
                                                       double *__restrict__ b, double *__restrict__ y) {
   extern __shared__ double lds[];
-  double *sA = lds, *sB = lds + NB * LDK, *ysh = lds + 4 * NB * LDK, *red = ysh + NB;
+  double *sA = lds, *sB = lds + NB * LDK, *ysh = lds + (DBUF ? 4 : 2) * NB * LDK, *red = ysh + NB;
   const int i = k + 1 + blockIdx.x;
   double *Sik = S + tile_index(i, k) * NB * NB;
   double *Vi = V + (int64_t)i * NB * NB;

@@ -6,6 +6,8 @@
 // Replaces (reference paths): src/BALNLPModels.jl:11-36,39-55,115-122 (residual), :125-158 (pattern),
 // :161-206 + src/JacobianByHand.jl:5-101 (values).  Compiled with -ffp-contract=off: Julia does not
 // contract a*b+c, and the parity tests bound the distance to the reference evaluation order in ulps.
+#include <cstdlib>
+
 #include "ba_internal.h"
 
 namespace {
@@ -104,13 +106,29 @@ __global__ __launch_bounds__(BLK) void k_jac_structure(int64_t nobs, int64_t npn
 // reference's padded 2x5 / 5x6 / 6x12 matrices (BALNLPModels.jl:177-197).  Entries of JP1/JP2/JP3 are
 // computed in T, the chain products in double (for T = Float32 the reference's scratch matrices are
 // Float64, BALNLPModels.jl:177,179).  Column order [X(3), r(3), t(3), k1, k2, f].
+// Unlike the residual (which keeps the reference's operation order), this block is tolerance-matched by
+// contract (the reference's own values depend on OpenBLAS' summation order, SURVEY.md 8c: <= 1e-12 of the
+// block inf-norm), so the ten divisions by theta and z are two reciprocals and a*b+c contracts to FMA.
 template <typename T>
 __device__ inline void jac_block(const T X[3], const T C[9], T J[24]) {
-  T P1[3], P2[2], out[2], th, s, c, kv[3], d;
-  project<T>(X, C, P1, P2, out, th, s, c, kv, d);
-  const T kx = kv[0], ky = kv[1], kz = kv[2];
+#pragma clang fp contract(fast)
   const T x = X[0], y = X[1], z = X[2];
-  const T sth = s / th, omc = 1 - c, omcth = (1 - c) / th;
+  const T th = Trig<T>::sq(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
+  const T ith = (T)1 / th;
+  const T kx = C[0] * ith, ky = C[1] * ith, kz = C[2] * ith;
+  T s, c;
+  Trig<T>::sc(th, s, c);
+  const T d = kx * x + ky * y + kz * z;
+  const T omc = 1 - c;
+  const T omc_d = omc * d;
+  T P1[3], P2[2];
+  P1[0] = ((c * x + s * (ky * z - kz * y)) + omc_d * kx) + C[3];
+  P1[1] = ((c * y + s * (kz * x - kx * z)) + omc_d * ky) + C[4];
+  P1[2] = ((c * z + s * (kx * y - ky * x)) + omc_d * kz) + C[5];
+  const T iz = (T)1 / P1[2];
+  P2[0] = -P1[0] * iz;
+  P2[1] = -P1[1] * iz;
+  const T sth = s * ith, omcth = omc * ith;
   const T kx2 = kx * kx, ky2 = ky * ky, kz2 = kz * kz;
   // JP1!  JacobianByHand.jl:27-59: R = d(P1)/dX (3x3), G = d(P1)/dr (3x3)
   T R[3][3], G[3][3];
@@ -142,9 +160,9 @@ __device__ inline void jac_block(const T X[3], const T C[9], T J[24]) {
   G[2][2] = -s * z * kz + c * kz * (kx * y - ky * x) + sth * (-kx * kz * y + kz * ky * x) + s * kz2 * d +
             omcth * (x * kx * (1 - 2 * kz2) + y * ky * (1 - 2 * kz2) + 2 * z * kz * (1 - kz2));
   // JP2!  JacobianByHand.jl:62-77
-  const T a = -1 / P1[2];
-  const T b0 = P1[0] / (P1[2] * P1[2]);
-  const T b1 = P1[1] / (P1[2] * P1[2]);
+  const T a = -iz;
+  const T b0 = P1[0] * iz * iz;
+  const T b1 = P1[1] * iz * iz;
   // JP3!  JacobianByHand.jl:80-101
   const T k1 = C[6], k2 = C[7], f = C[8];
   const T xx = P2[0], yy = P2[1];
@@ -190,64 +208,126 @@ __device__ inline void jac_block(const T X[3], const T C[9], T J[24]) {
   }
 }
 
-// jac_coord!: one lane per observation computes its 24 values in registers; the block's 256 x 24 values are
-// transposed through LDS (row stride 25 elements: conflict-free ds_write_b64 / ds_read_b64) so that every
-// wave store instruction writes 1 KiB of consecutive addresses.
+// jac_coord!: one lane per observation computes its 24 values in registers; each wave transposes its 64 x 24 values
+// through its own LDS slot (row stride 25 elements: conflict-free ds_write_b64 / ds_read_b64) so that every wave store
+// instruction writes 1 KiB of consecutive addresses.
+// Each wave handles NBW = 4 consecutive batches of 64 observations, straight-line (no loop: inside a loop the compiler
+// hoists the ~100 fp64 constants of sincos into registers, 240 VGPRs): the index pairs and the point/camera blocks of
+// ALL its batches are requested up front, so the index -> gather latency is paid once per 256 observations and the
+// stores of one batch drain while the next is computed.  Measured on Venice (5.0 M observations, 1.03 GB of HBM traffic
+// by the TCC counters = the algorithmic bytes): NBW 1 / 2 / 4 -> 0.295 / 0.285 / 0.260 ms; the arithmetic is free
+// (0.26 ms with it removed), the stores alone take 0.18 ms, the loads alone 0.07 ms.
+// DBG (tools/bench_jac.py only): 1 = skip the arithmetic, 2 = skip the stores.
+#ifndef BA_NBW
+#define BA_NBW 4
+#endif
+constexpr int NBW = BA_NBW;
+
+template <typename V, typename T>
+__device__ inline void stream_store16(T *p, V w) {
+  static_assert(sizeof(V) == 16, "16-byte store");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+}
+constexpr int CPAD = 16;  // camera rows are re-laid out to 16 elements (one 128-byte line for double) before the launch
+
+// x's camera block (9 per camera, 8-byte aligned rows) -> padded, 16-byte aligned rows.  Why: a lane fetching its camera
+// with nine 8-byte loads makes every one of the nine wave instructions pull 64 different cache lines through the CU's
+// 64 B/clk L1 fill path, which the 12 KB of stores per batch need as well (measured: gathers and stores add up, 0.29 ms);
+// five 16-byte loads of one aligned line fetch each line once.
 template <typename T>
+__global__ __launch_bounds__(BLK) void k_pad_cams(int64_t ncams, const T *__restrict__ cams, T *__restrict__ padded) {
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i >= ncams * CPAD) return;
+  int64_t c = i / CPAD;
+  int j = (int)(i - c * CPAD);
+  padded[i] = j < 9 ? cams[9 * c + j] : (T)0;
+}
+template <typename T, int DBG = 0>
 __global__ __launch_bounds__(BLK) void k_jac_coord(int64_t nobs, int64_t npnts, const int *__restrict__ cam0,
                                                     const int *__restrict__ pnt0, const T *__restrict__ x,
-                                                    T *__restrict__ vals) {
-  __shared__ T tile[BLK * 25];
-  const int t = threadIdx.x;
-  const int64_t o0 = (int64_t)blockIdx.x * BLK;
-  const int64_t o = o0 + t;
-  if (o < nobs) {
-    const T *Xp = x + 3 * (int64_t)pnt0[o];
-    const T *Cp = x + 3 * npnts + 9 * (int64_t)cam0[o];
-    T X[3], C[9], J[24];
-#pragma unroll
-    for (int i = 0; i < 3; i++) X[i] = Xp[i];
-#pragma unroll
-    for (int i = 0; i < 9; i++) C[i] = Cp[i];
-    jac_block<T>(X, C, J);
-#pragma unroll
-    for (int j = 0; j < 24; j++) tile[t * 25 + j] = J[j];
-  }
-  __syncthreads();
-  const int64_t nvalid = ((nobs - o0) < BLK ? (nobs - o0) : BLK) * 24;
-  T *out = vals + o0 * 24;
+                                                    const T *__restrict__ cpad, T *__restrict__ vals) {
+  __shared__ T tile[BLK / 64][64 * 25];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t w0 = ((int64_t)blockIdx.x * (BLK / 64) + wv) * (64 * NBW);  // first observation of this wave
+  if (w0 >= nobs) return;
   constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte store
+  T *ws = tile[wv];
+  T X[NBW][3], C[NBW][9];
+  int pi[NBW], ci[NBW];
 #pragma unroll
-  for (int it = 0; it < 24 / VEC; it++) {
-    int e = (it * BLK + t) * VEC;
-    if (e < nvalid) {
-      T v[VEC];
+  for (int q = 0; q < NBW; q++) {  // all index pairs first (one latency), then all gathers (one more)
+    int64_t o = w0 + 64 * q + lane;
+    o = o < nobs ? o : nobs - 1;
+    pi[q] = pnt0[o];
+    ci[q] = cam0[o];
+  }
 #pragma unroll
-      for (int q = 0; q < VEC; q++) {
-        int ee = e + q;
-        int oo = ee / 24;
-        v[q] = tile[oo * 25 + (ee - oo * 24)];
+  for (int q = 0; q < NBW; q++) {
+    const int p0 = pi[q], c0 = ci[q];
+#pragma unroll
+    for (int i = 0; i < 3; i++) X[q][i] = x[3 * (int64_t)p0 + i];
+    {
+      constexpr int VL = 16 / sizeof(T);  // elements per 16-byte load
+      typedef T vt __attribute__((ext_vector_type(VL)));
+      const vt *row = reinterpret_cast<const vt *>(cpad + CPAD * (int64_t)c0);
+      T tmp[((9 + VL - 1) / VL) * VL];
+#pragma unroll
+      for (int u = 0; u < (9 + VL - 1) / VL; u++) {
+        vt v = row[u];
+#pragma unroll
+        for (int e2 = 0; e2 < VL; e2++) tmp[u * VL + e2] = v[e2];
       }
-      if constexpr (sizeof(T) == 8) {
-        double2 w;
-        w.x = v[0];
-        w.y = v[1];
-        *reinterpret_cast<double2 *>(out + e) = w;
-      } else {
-        float4 w;
-        w.x = v[0];
-        w.y = v[1];
-        w.z = v[2];
-        w.w = v[3];
-        *reinterpret_cast<float4 *>(out + e) = w;
+#pragma unroll
+      for (int i = 0; i < 9; i++) C[q][i] = tmp[i];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NBW; q++) {
+    const int64_t b0 = w0 + 64 * q;
+    if (b0 >= nobs) break;
+    T J[24];
+    if (DBG & 1) {
+#pragma unroll
+      for (int j = 0; j < 24; j++) J[j] = X[q][j % 3] + C[q][j % 9];
+    } else {
+      jac_block<T>(X[q], C[q], J);
+    }
+    if (b0 + lane < nobs) {
+#pragma unroll
+      for (int j = 0; j < 24; j++) ws[lane * 25 + j] = J[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t nvalid = (nobs - b0) < 64 ? (nobs - b0) * 24 : 64 * 24;
+    T *out = vals + b0 * 24;
+#pragma unroll
+    for (int it = 0; it < 24 / VEC; it++) {
+      const int e = (it * 64 + lane) * VEC;
+      if (e < nvalid && !((DBG & 2) && ws[0] != (T)12345.678)) {
+        T v[VEC];
+#pragma unroll
+        for (int r = 0; r < VEC; r++) {
+          const int ee = e + r, oo = ee / 24;
+          v[r] = ws[oo * 25 + (ee - oo * 24)];
+        }
+        // write-through store that does NOT keep the line in the XCD's L2 (sc1): 960 MB of Jacobian streaming through
+        // the 4 MB L2s would otherwise keep evicting the camera table every lane gathers from
+        typedef T vst __attribute__((ext_vector_type(VEC)));
+        vst w;
+#pragma unroll
+        for (int r = 0; r < VEC; r++) w[r] = v[r];
+        stream_store16(out + e, w);
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 }  // namespace
 
 static inline unsigned grid_for(int64_t n, int blk) { return (unsigned)((n + blk - 1) / blk); }
+static inline unsigned jac_grid(int64_t nobs) { return grid_for(nobs, BLK * NBW); }
 
 int launch_residual_f64(ba_problem *p, const double *d_x, double *d_r, hipStream_t st) {
   if (p->nobs == 0) return BA_OK;
@@ -279,17 +359,56 @@ int launch_jac_structure(ba_problem *p, int64_t *d_rows, int64_t *d_cols, hipStr
 int launch_jac_coord_f64(ba_problem *p, const double *d_x, double *d_vals, hipStream_t st) {
   if (p->nobs == 0) return BA_OK;
   ProfScope ps(p, PC_JAC_COORD, st);
-  hipLaunchKernelGGL(k_jac_coord<double>, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0,
-                     p->pnt0, d_x, d_vals);
+  double *cpad = nullptr;
+  BA_CHECK(ba_scratch(p, 3, (size_t)(p->ncams * CPAD + 2) * sizeof(double), (void **)&cpad));
+  hipLaunchKernelGGL(k_pad_cams<double>, dim3(grid_for(p->ncams * CPAD, BLK)), dim3(BLK), 0, st, p->ncams,
+                     d_x + 3 * p->npnts, cpad);
+  hipLaunchKernelGGL(k_jac_coord<double>, dim3(jac_grid(p->nobs)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0,
+                     p->pnt0, d_x, (const double *)cpad, d_vals);
   BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+extern "C" int ba_debug_jac_bench(ba_problem *p, const double *d_x, double *d_vals, int variant, int reps, double *ms_out) {
+  hipEvent_t e0, e1;
+  BA_HIP_CHECK(hipSetDevice(p->device));
+  BA_HIP_CHECK(hipEventCreate(&e0));
+  BA_HIP_CHECK(hipEventCreate(&e1));
+  hipStream_t st = p->stream;
+  double *cpad = nullptr;
+  BA_CHECK(ba_scratch(p, 3, (size_t)(p->ncams * CPAD + 2) * sizeof(double), (void **)&cpad));
+  auto launch = [&]() {
+    dim3 g(jac_grid(p->nobs)), b(BLK);
+    hipLaunchKernelGGL(k_pad_cams<double>, dim3(grid_for(p->ncams * CPAD, BLK)), dim3(BLK), 0, st, p->ncams,
+                       d_x + 3 * p->npnts, cpad);
+#define JV(v) case v: hipLaunchKernelGGL((k_jac_coord<double, v>), g, b, 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_x, (const double *)cpad, d_vals); break;
+    switch (variant) {
+      JV(1) JV(2) JV(3)
+      default: hipLaunchKernelGGL((k_jac_coord<double, 0>), g, b, 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_x, (const double *)cpad, d_vals);
+    }
+#undef JV
+  };
+  launch();
+  BA_HIP_CHECK(hipStreamSynchronize(st));
+  BA_HIP_CHECK(hipEventRecord(e0, st));
+  for (int r = 0; r < reps; r++) launch();
+  BA_HIP_CHECK(hipEventRecord(e1, st));
+  BA_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / reps;
   return BA_OK;
 }
 
 int launch_jac_coord_f32(ba_problem *p, const float *d_x, float *d_vals, hipStream_t st) {
   if (p->nobs == 0) return BA_OK;
   ProfScope ps(p, PC_JAC_COORD, st);
-  hipLaunchKernelGGL(k_jac_coord<float>, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0,
-                     p->pnt0, d_x, d_vals);
+  float *cpad = nullptr;
+  BA_CHECK(ba_scratch(p, 3, (size_t)(p->ncams * CPAD + 2) * sizeof(double), (void **)&cpad));
+  hipLaunchKernelGGL(k_pad_cams<float>, dim3(grid_for(p->ncams * CPAD, BLK)), dim3(BLK), 0, st, p->ncams,
+                     d_x + 3 * p->npnts, cpad);
+  hipLaunchKernelGGL(k_jac_coord<float>, dim3(jac_grid(p->nobs)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0,
+                     p->pnt0, d_x, (const float *)cpad, d_vals);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
