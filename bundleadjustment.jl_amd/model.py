@@ -94,6 +94,9 @@ class BALNLPModel:
             self._h = C.c_void_p()
 
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():  # at interpreter exit the HIP context may already be gone: leak instead
+            return
         try:
             self.close()
         except Exception:

@@ -65,7 +65,8 @@ def gather_solution(x_local, info, ncams, group=None):
 class CameraBlockReducer:
     """Owns the reduce buffer of one shard (a torch tensor, so that torch.distributed can address it) and the
     all-reduce hook the C library calls (ba_lm_set_comm).  The hook sums buf[offset : offset+count] over the ranks in
-    place; on the GPU the collective is enqueued on the stream the library passes in."""
+    place.  With the NCCL (= RCCL) backend the collective is enqueued on the stream the library passes in; with gloo
+    (CPU tests, or several ranks sharing one GPU) the range is staged through pinned host memory."""
 
     def __init__(self, nlp, group=None):
         import torch
@@ -74,18 +75,33 @@ class CameraBlockReducer:
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
         n = C.c_int64(0)
         _lib.check(_lib.lib().ba_lm_reduce_doubles(nlp.handle, C.byref(n)))
         self.buf = torch.zeros(n.value, dtype=torch.float64, device=f"cuda:{nlp.device}")
         self.calls = 0
         self.bytes = 0
+        self._host = None
 
         def _hook(ctx, offset, count, stream):
             try:
                 view = self.buf[offset: offset + count]
                 ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
-                with torch.cuda.stream(ext):
-                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                if self.backend == "nccl":
+                    with torch.cuda.stream(ext):
+                        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    # host staging, fully synchronous, on torch's own stream (torch's pinned-memory allocator must not
+                    # record events on the library's stream: that stream dies with the handle)
+                    ext.synchronize()
+                    if self._host is None or self._host.numel() < count:
+                        self._host = torch.empty(max(count, 1 << 16), dtype=torch.float64).pin_memory()
+                    h = self._host[:count]
+                    h.copy_(view)
+                    torch.cuda.current_stream().synchronize()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                    view.copy_(h)
+                    torch.cuda.current_stream().synchronize()
                 self.calls += 1
                 self.bytes += 8 * count
                 return 0

@@ -1,0 +1,36 @@
+"""Run by torch.distributed.run with 2 ranks (gloo), both on cuda:0: sharded LM on the real kernels; rank 0 compares
+with the unsharded run and writes the verdict to argv[1]."""
+import json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+import torch, torch.distributed as dist
+
+def main():
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    ba = ge.load_package()
+    prob = ba.synthetic.make_problem(14, 600, 2700, seed=5)
+    arrays = ba.synthetic.as_arrays(prob)
+    local, info = ba.parallel.shard_problem(arrays, rank, world)
+    nlp = ba.BALNLPModel(arrays=local, device=0)
+    red = ba.parallel.CameraBlockReducer(nlp)
+    st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(nlp), "LDL", "AMD", "None", False)
+    x = ba.parallel.gather_solution(st.solution, info, prob["ncams"])
+    out = dict(rank=rank, iter=st.iter, objective=st.objective, status=st.status, calls=red.calls)
+    if rank == 0:
+        full = ba.BALNLPModel(arrays=arrays, device=0)
+        ref = ba.Levenberg_Marquardt(ba.FeasibilityResidual(full), "LDL", "AMD", "None", False)
+        out.update(ref_iter=ref.iter, ref_objective=ref.objective, ref_status=ref.status,
+                   dx=float(np.linalg.norm(x - ref.solution) / np.linalg.norm(ref.solution)),
+                   log_equal=[r[7] for r in st.log] == [r[7] for r in ref.log])
+        json.dump(out, open(sys.argv[1], "w"))
+        full.close()
+    nlp.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+if __name__ == "__main__":
+    main()
