@@ -39,7 +39,7 @@ __device__ inline int mfma_row(int lane, int reg) { return (lane >> 4) + 4 * reg
 // upper triangle of the LDS image.  Writes L (scaled, D on the diagonal) back in place, Linv and D.
 constexpr int LDA2 = 130;  // row stride 260 dwords = 4 mod 64: conflict-free MFMA operand reads
 constexpr int XDL = 18;
-constexpr size_t DIAG_LDS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB) * sizeof(double);
+constexpr size_t DIAG_LDS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB + 16 * 17) * sizeof(double);
 
 __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, double *__restrict__ Linv_k,
                                                    double *__restrict__ D_k, int *__restrict__ flag,
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
     tlast = tnow;                                          \
   }
   if (stamps) tlast = __builtin_amdgcn_s_memtime();
-  double *a = sm, *xd = sm + NB * LDA2, *dd = xd + 8 * 16 * XDL, *dinv = dd + NB;
+  double *a = sm, *xd = sm + NB * LDA2, *dd = xd + 8 * 16 * XDL, *dinv = dd + NB, *l16 = dinv + NB;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   // tile -> LDS: 16-byte loads, 8 in flight per thread; the strict upper triangle is zeroed
@@ -76,7 +76,6 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
   STAMP(0)
   for (int jb = 0; jb < 8; jb++) {
     const int o = 16 * jb;
-    double *xj = xd + jb * 16 * XDL;
     {  // unblocked LDL' of the diagonal block, one element per thread (a single-wave variant without the 16
        // workgroup barriers measured 40 us SLOWER per tile: the LDS round trips of one wave serialise)
       const int i = tid >> 4, c = tid & 15;
@@ -93,32 +92,29 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
       }
     }
     STAMP(1)
-    if (tid < 16) {  // column tid of the inverse of the unit-lower block, l[i][m] = a[i][m] * dinv[m]
-      const int c = tid;
-      double y[16];  // y[m] = dinv[m] * x[m]
+    // X = A(:,jb) L16^-T for the rows below the diagonal block by forward substitution, one row per thread (the rows
+    // are independent; X = L D stays unscaled).  L16 (scaled) is first copied to a small array so that every read of it
+    // is a broadcast.
+    if (tid < 256) {
+      const int i = tid >> 4, c = tid & 15;
+      l16[i * 17 + c] = (c < i) ? a[(o + i) * LDA2 + o + c] * dinv[o + c] : 0.0;
+    }
+    __syncthreads();
+    if (tid < NB - o - 16) {
+      const int r = o + 16 + tid;
+      double xr[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        double s = 0;
+      for (int c = 0; c < 16; c++) {
+        double sacc = a[r * LDA2 + o + c];
 #pragma unroll
-        for (int m = 0; m < i; m++) s += a[(o + i) * LDA2 + o + m] * y[m];
-        const double x = (i < c) ? 0.0 : (i == c ? 1.0 : -s);
-        y[i] = x * dinv[o + i];
-        xj[i * XDL + c] = x;
+        for (int m = 0; m < c; m++) sacc -= xr[m] * l16[c * 17 + m];
+        xr[c] = sacc;
       }
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[r * LDA2 + o + c] = xr[c];
     }
     __syncthreads();
     STAMP(2)
-    // X(I) = A(I,jb) * Linv16'
-    for (int I = jb + 1 + wv; I < 8; I += 4) {
-      d4 acc = {0, 0, 0, 0};
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(16 * I + fr) * LDA2 + o + 4 * kk + fk], xj[fr * XDL + 4 * kk + fk], acc,
-                                                   0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < 4; g++) a[(16 * I + mfma_row(lane, g)) * LDA2 + o + fr] = acc[g];
-    }
-    __syncthreads();
     // C(I,J) -= X(I) * (X(J) D^-1)'
     const int mb = 7 - jb, nblk = mb * (mb + 1) / 2;
     for (int t = wv; t < nblk; t += 4) {
@@ -141,6 +137,21 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
     __syncthreads();
     STAMP(3)
   }
+  if (tid < 128) {  // the eight 16x16 unit-lower inverses, one column per thread: l[i][m] = a[i][m] * dinv[m]
+    const int o = 16 * (tid >> 4), c = tid & 15;
+    double *xj = xd + (tid >> 4) * 16 * XDL;
+    double yv[16];  // yv[m] = dinv[m] * x[m]
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      double sacc = 0;
+#pragma unroll
+      for (int m = 0; m < i; m++) sacc += a[(o + i) * LDA2 + o + m] * yv[m];
+      const double xv = (i < c) ? 0.0 : (i == c ? 1.0 : -sacc);
+      yv[i] = xv * dinv[o + i];
+      xj[i * XDL + c] = xv;
+    }
+  }
+  __syncthreads();
   // full inverse: X(I,J) = -Linv16(I) * sum_{K=J}^{I-1} L(I,K) X(K,J); X(I,J)[i][j] kept at a[16J+j][16I+i]
   for (int I = 1; I < 8; I++) {
     for (int J = wv; J < I; J += 4) {
@@ -349,6 +360,186 @@ __global__ __launch_bounds__(256, 2) void k_ldl_trsm(double *__restrict__ S, con
       }
     __syncthreads();
     if (tid2 < NB) b[(int64_t)i * NB + tid2] -= red[tid2] + red[NB + tid2];
+  }
+}
+
+// ---- row-split panel kernels (latency path) ----------------------------------------------------------------------------
+// The panel solve and the one-column update have only (nt-k-1) tiles of work: one workgroup per tile leaves most CUs
+// idle and takes a full 128x128x128 product (27-33 us) on the critical path of every panel.  Here a workgroup owns
+// RS = 32 rows of a tile (4 waves x (32 rows x 32 columns) = 2x2 MFMA blocks each), so 4x as many workgroups run
+// concurrently and each is ~4x shorter.
+constexpr int RS = 32;
+constexpr size_t RS_LDS = (size_t)((RS + NB) * LDK + 5 * NB) * sizeof(double);
+
+template <bool YACC, int NP = 1>
+__device__ inline void tile_gemm_rows(const double *__restrict__ A, const double *__restrict__ B, double *sA, double *sB,
+                                      d4 acc[2][2], const double *__restrict__ bk, double *yacc,
+                                      const double *__restrict__ A1 = nullptr, const double *__restrict__ B1 = nullptr) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wc = wv * 32;
+  const int fr = lane & 15, fk = lane >> 4;
+  constexpr int UPR = KC / 2;
+  const int lrow = tid / UPR, lc2 = tid % UPR;  // 256 threads cover 32 rows x (KC/2) 16-byte units
+  d2 pa, pb[4];
+  pa = *reinterpret_cast<const d2 *>(A + lrow * NB + 2 * lc2);
+#pragma unroll
+  for (int it = 0; it < 4; it++) pb[it] = *reinterpret_cast<const d2 *>(B + (lrow + 32 * it) * NB + 2 * lc2);
+  constexpr int NCH = NP * (NB / KC);
+  for (int ch = 0; ch < NCH; ch++) {
+    __syncthreads();
+    *reinterpret_cast<d2 *>(sA + lrow * LDK + 2 * lc2) = pa;
+#pragma unroll
+    for (int it = 0; it < 4; it++) *reinterpret_cast<d2 *>(sB + (lrow + 32 * it) * LDK + 2 * lc2) = pb[it];
+    __syncthreads();
+    if (ch + 1 < NCH) {
+      const int nx = ch + 1;
+      const double *An = (NP == 2 && nx >= NB / KC) ? A1 : A;
+      const double *Bn = (NP == 2 && nx >= NB / KC) ? B1 : B;
+      const int k0 = (nx & (NB / KC - 1)) * KC;
+      pa = *reinterpret_cast<const d2 *>(An + lrow * NB + k0 + 2 * lc2);
+#pragma unroll
+      for (int it = 0; it < 4; it++) pb[it] = *reinterpret_cast<const d2 *>(Bn + (lrow + 32 * it) * NB + k0 + 2 * lc2);
+    }
+    if (YACC) {
+      if (tid < NB) {
+        double ya = *yacc;
+#pragma unroll
+        for (int q = 0; q < KC; q++) ya += sB[tid * LDK + q] * bk[ch * KC + q];
+        *yacc = ya;
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; kk++) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++) af[m] = sA[(16 * m + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+      for (int n = 0; n < 2; n++) bf[n] = sB[(wc + 16 * n + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+  }
+}
+
+// rows [32 rq, 32 rq + 32) of X_i = S_ik Linv_k' -> V_i, S_ik = X_i D_k^-1; FWD: y_k and b_i -= L_ik y_k ride along.
+// grid = 4 (nt-k-1): i = k + 1 + blockIdx.x / 4, rq = blockIdx.x % 4
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_ldl_trsm_rs(double *__restrict__ S, const double *__restrict__ Linv_k,
+                                                      const double *__restrict__ D_k, double *__restrict__ V, int k,
+                                                      double *__restrict__ b, double *__restrict__ y) {
+  extern __shared__ double lds[];
+  double *sA = lds, *sB = lds + RS * LDK, *ysh = lds + (RS + NB) * LDK, *red = ysh + NB;  // red: 4 x 32
+  const int i = k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
+  double *Sik = S + tile_index(i, k) * NB * NB + r0 * NB;
+  double *Vi = V + (int64_t)i * NB * NB + r0 * NB;
+  d4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  double yacc = 0;
+  tile_gemm_rows<FWD>(Sik, Linv_k, sA, sB, acc, FWD ? b + (int64_t)k * NB : nullptr, &yacc);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wc = wv * 32;
+  if (FWD) {
+    if (tid < NB) {
+      ysh[tid] = yacc;
+      if (blockIdx.x == 0) y[(int64_t)k * NB + tid] = yacc;
+    }
+    __syncthreads();
+  }
+  double part[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) part[m][g] = 0;
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int col = wc + 16 * n + (lane & 15);
+    const double inv_d = 1.0 / D_k[col];
+    const double wcol = FWD ? ysh[col] * inv_d : 0.0;
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = 16 * m + mfma_row(lane, g);
+        const double xv = acc[m][n][g];
+        Vi[row * NB + col] = xv;
+        Sik[row * NB + col] = xv * inv_d;
+        if (FWD) part[m][g] += xv * wcol;
+      }
+  }
+  if (FWD) {
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        double v = part[m][g];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if ((lane & 15) == 0) red[wv * RS + 16 * m + mfma_row(lane, g)] = v;
+      }
+    __syncthreads();
+    if (tid < RS) b[(int64_t)i * NB + r0 + tid] -= ((red[tid] + red[RS + tid]) + red[2 * RS + tid]) + red[3 * RS + tid];
+  }
+}
+
+// rows [32 rq, 32 rq + 32) of S_{i,k+1} -= V0_i L_{k+1,k}'   (grid = 4 (nt-k-1))
+__global__ __launch_bounds__(256) void k_ldl_col_rs(double *__restrict__ S, const double *__restrict__ V0, int k) {
+  extern __shared__ double lds[];
+  double *sA = lds, *sB = lds + RS * LDK;
+  const int i = k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
+  d4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  tile_gemm_rows<false>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(k + 1, k) * NB * NB, sA, sB, acc, nullptr, nullptr);
+  const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) * 32;
+  double *Sij = S + tile_index(i, k + 1) * NB * NB + r0 * NB;
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int col = wc + 16 * n + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = 16 * m + mfma_row(lane, g);
+        Sij[row * NB + col] -= acc[m][n][g];
+      }
+  }
+}
+
+// rows [32 rq, 32 rq + 32) of S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' for the two tile columns j = base, base+1 (what the
+// next two panels need first).  grid = 4 (2m - 1), m = nt - base: tiles (base+t, base) for t < m, then (base+1+t', base+1)
+__global__ __launch_bounds__(256) void k_ldl_pair2_rs(double *__restrict__ S, const double *__restrict__ V0,
+                                                       const double *__restrict__ V1, int k, int base, int nt) {
+  extern __shared__ double lds[];
+  double *sA = lds, *sB = lds + RS * LDK;
+  const int m = nt - base, t = blockIdx.x >> 2, r0 = (blockIdx.x & 3) * RS;
+  const int i = t < m ? base + t : base + 1 + (t - m), j = t < m ? base : base + 1;
+  d4 acc[2][2];
+#pragma unroll
+  for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+    for (int n = 0; n < 2; n++) acc[mm][n] = (d4){0, 0, 0, 0};
+  tile_gemm_rows<false, 2>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(j, k) * NB * NB, sA, sB, acc, nullptr, nullptr,
+                           V1 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(j, k + 1) * NB * NB);
+  const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) * 32;
+  double *Sij = S + tile_index(i, j) * NB * NB + r0 * NB;
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int col = wc + 16 * n + (lane & 15);
+#pragma unroll
+    for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = 16 * mm + mfma_row(lane, g);
+        Sij[row * NB + col] -= acc[mm][n][g];
+      }
   }
 }
 
@@ -614,10 +805,10 @@ static int launch_trsm(ba_problem *p, DenseLDL *w, int k, double *V, double *b, 
   }
   ProfScope ps(p, PC_LDL_TRSM, st);
   if (b)
-    hipLaunchKernelGGL(k_ldl_trsm<true>, dim3(m), dim3(256), TRSM_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
+    hipLaunchKernelGGL(k_ldl_trsm_rs<true>, dim3(4 * m), dim3(256), RS_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
                        w->D + (int64_t)k * NB, V, k, b, y);
   else
-    hipLaunchKernelGGL(k_ldl_trsm<false>, dim3(m), dim3(256), TRSM_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
+    hipLaunchKernelGGL(k_ldl_trsm_rs<false>, dim3(4 * m), dim3(256), RS_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
                        w->D + (int64_t)k * NB, V, k, b, y);
   return BA_OK;
 }
@@ -626,7 +817,7 @@ static int launch_col(ba_problem *p, DenseLDL *w, int k, const double *V0, hipSt
   const int m = (int)w->nt - k - 1;
   if (m <= 0) return BA_OK;
   ProfScope ps(p, PC_LDL_SYRK, st);
-  hipLaunchKernelGGL(k_ldl_update<0>, dim3(m), dim3(256), GEMM_LDS, st, w->S, V0, V0, k, k + 1, (int)w->nt, m);
+  hipLaunchKernelGGL(k_ldl_col_rs, dim3(4 * m), dim3(256), RS_LDS, st, w->S, V0, k);
   return BA_OK;
 }
 
@@ -638,7 +829,7 @@ static int launch_pair(ba_problem *p, DenseLDL *w, int k, int base, bool first2,
   ProfScope ps(p, PC_LDL_SYRK, st);
   if (first2) {
     const int nblk = m + (m > 1 ? m - 1 : 0);
-    hipLaunchKernelGGL(k_ldl_update<2>, dim3(nblk), dim3(256), GEMM_LDS, st, w->S, V0, V1, k, base, nt, nblk);
+    hipLaunchKernelGGL(k_ldl_pair2_rs, dim3(4 * nblk), dim3(256), RS_LDS, st, w->S, V0, V1, k, base, nt);
   } else {
     const int nblk = m * (m + 1) / 2;
     hipLaunchKernelGGL(k_ldl_update<1>, dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_LDS, st, w->S, V0, V1, k, base, nt, nblk);
