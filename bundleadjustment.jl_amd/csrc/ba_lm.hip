@@ -181,6 +181,7 @@ static int lm_ensure(ba_problem *p) {
   BA_CHECK(dmalloc(&w->u, 3 * npnts));
   BA_CHECK(dmalloc(&w->Yobs, 6 * nobs));
   BA_CHECK(dmalloc(&w->Hcc, 45 * ncams));
+  BA_CHECK(dmalloc(&w->colscale, 9 * ncams));
   BA_CHECK(dmalloc(&w->partial, (int64_t)RED_BLOCKS));
   BA_CHECK(dmalloc(&w->s.scal_rep, (int64_t)RP_COUNT));
   BA_HIP_CHECK(hipHostMalloc((void **)&w->s.h_sh, SH_COUNT * sizeof(double)));
@@ -240,7 +241,7 @@ static int fetch_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 }
 
 // delta = -(J'J + lambda I)^-1 J'r at the current linearisation; also |J delta + r|^2 -> SH_MODEL, |delta|^2
-static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, hipStream_t st) {
+static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, hipStream_t st) {
   // every rank holds partial Hcc / Schur sums; the lambda I of the camera block is added by rank 0 only
   const double lam_diag = (p->rank == 0) ? lambda : 0.0;
   BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st));
@@ -249,10 +250,17 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, hipStream_t 
   BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
   BA_CHECK(launch_schur_rhs(p, w->J, w->r, w->u, w->rhs, st));
   BA_CHECK(comm_sum(p, w, 0, w->s.off_gc, st));  // S tiles and rhs are adjacent
+  if (normalize != 0) {  // :J / :A column scaling of the camera system (Hcc must be the global sum: multi-GPU runs
+                         // reduce it with gc, see refresh_linearisation)
+    BA_CHECK(launch_cam_scale(p, w->Hcc, normalize == 2 ? lambda : 0.0, w->colscale, st));
+    BA_CHECK(launch_scale_S(p, w->n, w->ldl.nt, w->colscale, w->ldl.S, st));
+    BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));
+  }
   int zp = 0;
   BA_CHECK(dense_ldl_factor(p, &w->ldl, st, nullptr, w->rhs));  // forward substitution of rhs rides along
   BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st, true));
   double *dc = w->delta + 3 * p->npnts;
+  if (normalize != 0) BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));  // dc = D^-1 dc'
   BA_HIP_CHECK(hipMemcpyAsync(dc, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
   BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->u, dc, w->delta, st));
   (void)zp;
@@ -322,7 +330,7 @@ extern "C" int ba_lm_step(ba_problem *p, const double *x, double lambda, double 
   hipStream_t st = p->stream;
   BA_HIP_CHECK(hipMemcpyAsync(w->x, x, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
   BA_CHECK(refresh_linearisation(p, w, true, st));
-  BA_CHECK(linear_step(p, w, lambda, st));
+  BA_CHECK(linear_step(p, w, lambda, 0, st));
   BA_CHECK(check_pivot(p, w, st));
   BA_CHECK(step_scalars(p, w, st));
   BA_CHECK(comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st));
@@ -345,6 +353,14 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   }
   if (o->variant != 0 && o->variant != 1) {
     ba_set_error("ba_lm_solve: variant must be 0 (LevenbergMarquardt.jl) or 1 (lm.jl)");
+    return BA_ERR_ARG;
+  }
+  if (o->normalize < 0 || o->normalize > 2) {
+    ba_set_error("ba_lm_solve: normalize must be 0 (:None), 1 (:J) or 2 (:A)");
+    return BA_ERR_ARG;
+  }
+  if (o->normalize != 0 && p->world > 1) {
+    ba_set_error("ba_lm_solve: normalize != :None is single-GPU only for now (Hcc is not all-reduced)");
     return BA_ERR_ARG;
   }
   if (o->facto_f32) {
@@ -398,7 +414,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   while (!(small_step || first_order || small_residual || small_obj_change || tired || fail2)) {
     if (V) iter++;                                                                           // lm.jl:127
     if (!V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);  // LevenbergMarquardt.jl:143-147
-    if ((rc = linear_step(p, w, lambda, st)) != BA_OK) break;
+    if ((rc = linear_step(p, w, lambda, o->normalize, st)) != BA_OK) break;
     stats->n_factor++;
     if ((rc = step_scalars(p, w, st)) != BA_OK) break;
     if ((rc = trial_point(p, w, st)) != BA_OK) break;  // lm.jl:251-254

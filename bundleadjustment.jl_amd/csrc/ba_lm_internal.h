@@ -45,5 +45,7 @@ int launch_model_sq(ba_problem *p, const double *d_J, const double *d_r, const d
 int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial, double *d_scal, int slot,
                  hipStream_t st);
 int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st);
+int launch_cam_scale(ba_problem *p, const double *d_Hcc, double add, double *d_dsc, hipStream_t st);
+int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, double *d_S, hipStream_t st);
 int launch_scale_scalar(ba_problem *p, int64_t n, double *d_v, double alpha, hipStream_t st);
 int launch_scale_vec(ba_problem *p, int64_t n, const double *d_s, double *d_v, int divide, hipStream_t st);

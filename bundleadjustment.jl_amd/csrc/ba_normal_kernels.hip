@@ -255,6 +255,35 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
   }
 }
 
+// Column scaling of the reduced camera system (normalize = :J / :A, reference: src/lma_aux.jl:102-154): the reference
+// scales the columns of J by their 2-norms (:J) or those of [J; sqrt(lambda) I] (:A) before factorising.  The point
+// columns are eliminated in closed 3x3 form here, so only the camera columns matter: d_j = sqrt(diag(Hcc)_j [+ lambda]),
+// S <- D^-1 S D^-1, rhs <- D^-1 rhs, and afterwards dc <- D^-1 dc'.  Same step in exact arithmetic, better conditioned.
+__global__ __launch_bounds__(BLK) void k_cam_scale(int64_t ncams, const double *__restrict__ Hcc, double add,
+                                                    double *__restrict__ dsc) {
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i >= 9 * ncams) return;
+  int64_t c = i / 9;
+  int j = (int)(i - 9 * c);
+  double v = sqrt(Hcc[45 * c + j * (j + 1) / 2 + j] + add);
+  dsc[i] = (v != 0.0) ? v : 1.0;  // col_norms[j] == 0 columns are left alone (lma_aux.jl:120,148)
+}
+
+// one workgroup per stored tile: S_ij /= d_i d_j   (padding rows/columns have d = 1)
+__global__ __launch_bounds__(BLK) void k_scale_S(int64_t n, int64_t nt, const double *__restrict__ dsc, double *__restrict__ S) {
+  const int64_t t = blockIdx.x;
+  int64_t ti = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+  while (ti * (ti + 1) / 2 > t) ti--;
+  const int64_t tj = t - ti * (ti + 1) / 2;
+  double *T = S + t * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += BLK) {
+    const int64_t r = ti * NB + (e >> 7), c = tj * NB + (e & (NB - 1));
+    const double dr = r < n ? dsc[r] : 1.0, dc = c < n ? dsc[c] : 1.0;
+    T[e] /= dr * dc;
+  }
+}
+
 // unit diagonal on the padding rows n..npad-1 so that the padded matrix stays factorisable
 __global__ void k_pad_diag(int64_t n, int64_t npad, double *S) {
   int64_t i = n + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -409,6 +438,19 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
     hipLaunchKernelGGL(k_schur_blocks, dim3(grid_for(T->nkeys, BLK / 64)), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
                        T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_S);
   if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_cam_scale(ba_problem *p, const double *d_Hcc, double add, double *d_dsc, hipStream_t st) {
+  if (p->ncams == 0) return BA_OK;
+  hipLaunchKernelGGL(k_cam_scale, dim3(grid_for(9 * p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_Hcc, add, d_dsc);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, double *d_S, hipStream_t st) {
+  hipLaunchKernelGGL(k_scale_S, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(BLK), 0, st, n, nt, d_dsc, d_S);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }

@@ -222,6 +222,19 @@ def test_lm_solve_vs_oracle(ba, orc, small_prob, gpu_ok, variant):
     m.close()
 
 
+@pytest.mark.parametrize("norm,code", [("J", 1), ("A", 2)])
+def test_lm_normalize_vs_oracle(ba, orc, small_prob, gpu_ok, norm, code):
+    """normalize = :J / :A (src/lma_aux.jl:102-154): a preconditioning, same iterates up to rounding."""
+    p = small_prob
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "LDL", "AMD", norm, False)
+    rc, x_ref, st_ref, log_ref = orc.lm_solve(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"],
+                                              variant=1, normalize=code)
+    assert rc == 0 and st.iter == st_ref.iter and st.status == orc.STATUS[st_ref.status]
+    assert abs(st.objective - st_ref.objective) <= 1e-8 * st_ref.objective
+    m.close()
+
+
 def test_lm_linesearch_vs_oracle(ba, orc, small_prob, gpu_ok):
     p = small_prob
     m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
