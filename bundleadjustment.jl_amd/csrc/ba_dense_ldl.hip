@@ -294,6 +294,66 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
   }
 }
 
+// Wave-private variant: every wave stages the 64 A rows and 64 B rows IT needs in its own LDS region, so the K loop has
+// no workgroup barrier at all (each operand slice is loaded by the two waves that use it: 2x the L2->LDS traffic, which
+// is not the limiter).  LDS: 4 waves x 128 rows x 18 doubles = 73.7 KB.
+constexpr size_t GEMM_PRIV_LDS = (size_t)4 * 2 * 64 * LDK * sizeof(double);
+template <int NP>
+__device__ inline void tile_gemm_abt_priv(const double *__restrict__ A0, const double *__restrict__ B0,
+                                          const double *__restrict__ A1, const double *__restrict__ B1, double *lds,
+                                          d4 acc[4][4]) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  const int fr = lane & 15, fk = lane >> 4;
+  double *sA = lds + wv * (2 * 64 * LDK), *sB = sA + 64 * LDK;
+  constexpr int UPR = KC / 2;       // 16-byte units per row of a chunk (8)
+  constexpr int RPS = 64 / UPR;     // rows per step of the 64 lanes (8)
+  constexpr int NLD = 64 / RPS;     // steps to cover 64 rows (8)
+  const int lrow = lane / UPR, lc2 = lane % UPR;
+  d2 pa[NLD], pb[NLD];
+  const double *Ab = A0 + wr * NB, *Bb = B0 + wc * NB;
+#pragma unroll
+  for (int it = 0; it < NLD; it++) {
+    pa[it] = *reinterpret_cast<const d2 *>(Ab + (lrow + RPS * it) * NB + 2 * lc2);
+    pb[it] = *reinterpret_cast<const d2 *>(Bb + (lrow + RPS * it) * NB + 2 * lc2);
+  }
+  constexpr int NCH = NP * (NB / KC);
+  for (int ch = 0; ch < NCH; ch++) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NLD; it++) {
+      *reinterpret_cast<d2 *>(sA + (lrow + RPS * it) * LDK + 2 * lc2) = pa[it];
+      *reinterpret_cast<d2 *>(sB + (lrow + RPS * it) * LDK + 2 * lc2) = pb[it];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nx = ch + 1;
+    if (nx < NCH) {
+      const double *A = ((NP == 2 && nx >= NB / KC) ? A1 : A0) + wr * NB;
+      const double *B = ((NP == 2 && nx >= NB / KC) ? B1 : B0) + wc * NB;
+      const int k0 = (nx & (NB / KC - 1)) * KC;
+#pragma unroll
+      for (int it = 0; it < NLD; it++) {
+        pa[it] = *reinterpret_cast<const d2 *>(A + (lrow + RPS * it) * NB + k0 + 2 * lc2);
+        pb[it] = *reinterpret_cast<const d2 *>(B + (lrow + RPS * it) * NB + k0 + 2 * lc2);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; kk++) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+      for (int n = 0; n < 4; n++) bf[n] = sB[(16 * n + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+  }
+}
+
 // X_i = S_ik * Linv_k'  ->  V_i = X_i,  S_ik = X_i * D_k^-1      (i = k+1+blockIdx.x)
 // FWD: the forward substitution of one right-hand side rides along: y_k = Linv_k b_k (every workgroup, from the B
 // chunks; block 0 stores it) and b_i -= L_ik y_k from the accumulators.
@@ -548,7 +608,8 @@ __global__ __launch_bounds__(256) void k_ldl_pair2_rs(double *__restrict__ S, co
 // trailing matrix is read and written once per TWO panels, which halves its HBM traffic per flop.
 // MODE 2 (pair, the two tile columns base and base+1 only): what the next two panels need first (look-ahead).
 // DBG (micro-benchmark only, ba_debug_update_bench): bit 0 = store instead of read-modify-write, bit 1 = every
-// workgroup reads the same operand tiles (L2-resident operands).
+// workgroup reads the same operand tiles (L2-resident operands), bit 3 = workgroup-shared LDS staging with barriers
+// (the first version: 52.6 TFLOP/s against 59.8 for the wave-private staging that ships).
 template <int MODE, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, const double *__restrict__ V0,
                                                         const double *__restrict__ V1, int k, int base, int nt,
@@ -591,6 +652,9 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, c
   const int io = (DBG & 2) ? base : i, jo = (DBG & 2) ? base : j;
   if (MODE == 0)
     tile_gemm_abt<1>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, nullptr, nullptr, sA, sB, acc);
+  else if (!(DBG & 8))
+    tile_gemm_abt_priv<2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                          S + tile_index(jo, k + 1) * NB * NB, lds, acc);
   else
     tile_gemm_abt<2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
                      S + tile_index(jo, k + 1) * NB * NB, sA, sB, acc);
@@ -711,14 +775,16 @@ static int set_kernel_attrs() {
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_PRIV_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_PRIV_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_PRIV_LDS));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 8>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 3>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 9>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
   g_attr_done = true;
   return BA_OK;
@@ -738,10 +804,14 @@ int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S) {
   }
   BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(double)));  // 2 x two panels of L*D
   {
-    // Look-ahead needs the latency-bound panel chain to run BESIDE the bulk update, but the bulk GEMM fills every
-    // CU's register file, so the chain's workgroups would queue behind it.  Give each its own CUs: the side stream gets
-    // `side_cus` CUs (spread over the XCDs by taking every (256/side_cus)-th bit), the bulk stream the rest.
-    int side_cus = 32;
+    // Look-ahead needs the latency-bound panel chain to run BESIDE the bulk update.  Its GEMM-shaped kernels only need
+    // workgroup slots as they free up, so they go to a HIGH-PRIORITY stream; the one-workgroup diagonal-tile kernel needs a
+    // whole CU's LDS, which the bulk update (2 workgroups and all 512 registers per SIMD on every CU) never leaves free,
+    // so the bulk stream's CU mask excludes `side_cus` CUs (BA_LDL_SIDE_CUS).  Measured on Venice (n = 16002): 39.0 ms
+    // without look-ahead, 40-51 ms with 2-16 reserved CUs (and 41.7 vs 42.3 ms for the earlier 32-CU two-mask variant):
+    // the panel chain is short enough after the row-split kernels that the partition costs more than it hides, so the
+    // default is OFF (0) and the whole factorisation runs on the caller's stream.
+    int side_cus = 0;
     if (const char *e = getenv("BA_LDL_SIDE_CUS")) side_cus = atoi(e);
     hipDeviceProp_t prop;
     int dev = 0;
@@ -750,16 +820,18 @@ int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S) {
     const int ncu = prop.multiProcessorCount;
     w->side_cus = 0;
     if (side_cus > 0 && side_cus < ncu && ncu <= 1024) {
-      uint32_t m_side[32] = {0}, m_bulk[32] = {0};
+      uint32_t m_bulk[32] = {0};
       const int stride = ncu / side_cus;
       int cnt = 0;
       for (int c = 0; c < ncu; c++) {
         const bool s_ = (c % stride == 0) && cnt < side_cus;
         if (s_) cnt++;
-        (s_ ? m_side : m_bulk)[c / 32] |= 1u << (c % 32);
+        else m_bulk[c / 32] |= 1u << (c % 32);
       }
       const uint32_t words = (uint32_t)((ncu + 31) / 32);
-      if (hipExtStreamCreateWithCUMask(&w->side, words, m_side) == hipSuccess &&
+      int pr_lo = 0, pr_hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+      if (hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, pr_hi) == hipSuccess &&
           hipExtStreamCreateWithCUMask(&w->bulk, words, m_bulk) == hipSuccess)
         w->side_cus = cnt;
       else
@@ -832,7 +904,7 @@ static int launch_pair(ba_problem *p, DenseLDL *w, int k, int base, bool first2,
     hipLaunchKernelGGL(k_ldl_pair2_rs, dim3(4 * nblk), dim3(256), RS_LDS, st, w->S, V0, V1, k, base, nt);
   } else {
     const int nblk = m * (m + 1) / 2;
-    hipLaunchKernelGGL(k_ldl_update<1>, dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_LDS, st, w->S, V0, V1, k, base, nt, nblk);
+    hipLaunchKernelGGL(k_ldl_update<1>, dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS, st, w->S, V0, V1, k, base, nt, nblk);
   }
   return BA_OK;
 }
@@ -996,10 +1068,11 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   auto launch = [&]() {
     const double *V0 = V, *V1 = V + (size_t)nt * NB * NB;
     switch (variant) {
-      case 1: hipLaunchKernelGGL((k_ldl_update<1, 1>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
-      case 2: hipLaunchKernelGGL((k_ldl_update<1, 2>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
-      case 3: hipLaunchKernelGGL((k_ldl_update<1, 3>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
-      default: hipLaunchKernelGGL((k_ldl_update<1, 0>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk);
+      case 1: hipLaunchKernelGGL((k_ldl_update<1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
+      case 2: hipLaunchKernelGGL((k_ldl_update<1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
+      case 8: hipLaunchKernelGGL((k_ldl_update<1, 8>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
+      case 9: hipLaunchKernelGGL((k_ldl_update<1, 9>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
+      default: hipLaunchKernelGGL((k_ldl_update<1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS, 0, S, V0, V1, 0, 2, nt, nblk);
     }
   };
   {

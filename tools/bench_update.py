@@ -1,5 +1,6 @@
 """Micro-benchmark of the bulk trailing update kernel (K = 256 pair update) on an nt x nt tile matrix.
-variants: 0 real, 1 store-only epilogue, 2 shared (L2-resident) operands, 3 both."""
+variants: 0 real (wave-private LDS staging), 1 store-only epilogue, 2 L2-resident operands, 8 workgroup-shared staging
+with barriers (first version), 9 = 8 + store-only."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
@@ -9,7 +10,7 @@ nt = int(sys.argv[1]) if len(sys.argv) > 1 else 126
 L.ba_debug_update_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 m = nt - 2
 flops = m * (m + 1) / 2 * 2 * 128 * 128 * 256
-for v in (0, 1, 2, 3, 0):
+for v in (0, 1, 2, 8, 9, 0):
     ms = C.c_double(0)
     rc = L.ba_debug_update_bench(nt, v, 5, C.byref(ms))
     print(f"variant {v}: {ms.value:.3f} ms  {flops / ms.value / 1e9:.1f} TFLOP/s (rc {rc})", flush=True)
