@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only; invalid as a result)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--backend", default=os.environ.get("BA_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend: nccl (= RCCL, default) or gloo (host-staged all-reduce; rehearsal only)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (several ranks sharing one GPU need --backend gloo)")
     return ap.parse_args()
 
 
@@ -56,10 +60,16 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    torch.zeros(1, device="cuda")  # initialise torch's HIP context before c10d counts the devices
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=args.backend)
     ba = ge.load_package()
 
     # ---- workload ---------------------------------------------------------------------------------------------------
@@ -88,10 +98,14 @@ def main():
     st = lm_fixed_iterations(ba, fr, args.steps)
     barrier()
     elapsed = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    def max_over_ranks(v):
+        if world <= 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    elapsed = max_over_ranks(elapsed)
     assert st.iter == args.steps, (st.iter, args.steps)
 
     # ---- Jacobian throughput: jac_coord on device-resident x / vals, events on the launch stream ---------------------
@@ -116,10 +130,7 @@ def main():
     e1.record(stream)
     torch.cuda.synchronize()
     jac_ms = e0.elapsed_time(e1) / reps
-    if world > 1:
-        t = torch.tensor([jac_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        jac_ms = float(t.item())
+    jac_ms = max_over_ranks(jac_ms)
     jac_mnnz = 24.0 * nobs_g / (jac_ms * 1e-3) / 1e6
     # algorithmic bytes of jac_coord!: 2 int64 indices + 24 doubles out + every parameter read once
     jac_bytes = (208.0 + 8.0 * nvar_g / nobs_g) * nobs_g / world
@@ -184,7 +195,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "LM iterations/sec on BAL Venice-1778 (synthetic BAL-shaped), plus Jacobian Mnnz/sec",
+            "metric": f"LM iterations/sec on BAL {args.workload} (synthetic BAL-shaped), plus Jacobian Mnnz/sec",
             "value": args.steps / elapsed,
             "unit": "LM iterations/s",
             "n_gpus": world,

@@ -7,10 +7,13 @@
 //
 // Storage: lower block triangle of NB x NB (128) tiles, each tile contiguous row-major (ba_internal.h).
 // Right-looking, one panel (tile column) per step k:
-//   k_ldl_diag : one workgroup factors tile (k,k) in LDS (L_kk, D_k) and forms L_kk^-1 explicitly;
-//   k_ldl_trsm : X_i = S_ik L_kk^-T  (= L_ik D_k) as an MFMA GEMM with L_kk^-1, stores V_i = X_i and L_ik = X_i D_k^-1;
-//   k_ldl_syrk : S_ij -= V_i L_jk' for k < j <= i, MFMA GEMM (v_mfma_f64_16x16x4_f64), the n^3/3 flops.
-// Solves: forward sweep by tile columns, diagonal scaling folded into the backward sweep by tile rows.
+//   k_ldl_diag     : one workgroup factors tile (k,k) in LDS (L_kk, D_k) and forms L_kk^-1 explicitly;
+//   k_ldl_trsm_rs  : X_i = S_ik L_kk^-T (= L_ik D_k) as an MFMA product with L_kk^-1 (32 rows per workgroup), stores
+//                    V_i = X_i and L_ik = X_i D_k^-1; the forward substitution of the right-hand side rides along;
+//   k_ldl_col_rs / k_ldl_pair2_rs : the updates the NEXT panels need (one / two tile columns);
+//   k_ldl_update<1>: S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' for the rest, two panels per pass (v_mfma_f64_16x16x4_f64):
+//                    the n^3/3 flops.
+// Solves: forward substitution fused into the panel solves, diagonal scaling folded into the backward sweep by tile rows.
 #include "ba_internal.h"
 
 #include <cmath>
@@ -354,75 +357,6 @@ __device__ inline void tile_gemm_abt_priv(const double *__restrict__ A0, const d
   }
 }
 
-// X_i = S_ik * Linv_k'  ->  V_i = X_i,  S_ik = X_i * D_k^-1      (i = k+1+blockIdx.x)
-// FWD: the forward substitution of one right-hand side rides along: y_k = Linv_k b_k (every workgroup, from the B
-// chunks; block 0 stores it) and b_i -= L_ik y_k from the accumulators.
-constexpr size_t TRSM_LDS = GEMM_LDS + (size_t)3 * NB * sizeof(double);
-template <bool FWD>
-__global__ __launch_bounds__(256, 2) void k_ldl_trsm(double *__restrict__ S, const double *__restrict__ Linv_k,
-                                                      const double *__restrict__ D_k, double *__restrict__ V, int k,
-                                                      double *__restrict__ b, double *__restrict__ y) {
-  extern __shared__ double lds[];
-  double *sA = lds, *sB = lds + NB * LDK, *ysh = lds + (DBUF ? 4 : 2) * NB * LDK, *red = ysh + NB;
-  const int i = k + 1 + blockIdx.x;
-  double *Sik = S + tile_index(i, k) * NB * NB;
-  double *Vi = V + (int64_t)i * NB * NB;
-  d4 acc[4][4];
-#pragma unroll
-  for (int m = 0; m < 4; m++)
-#pragma unroll
-    for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
-  double yacc = 0;
-  tile_gemm_abt<1, FWD>(Sik, Linv_k, nullptr, nullptr, sA, sB, acc, FWD ? b + (int64_t)k * NB : nullptr, &yacc);
-  int tid2 = threadIdx.x;
-  asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
-  const int lane = tid2 & 63, wv = tid2 >> 6;
-  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
-  if (FWD) {
-    if (tid2 < NB) {
-      ysh[tid2] = yacc;
-      if (blockIdx.x == 0) y[(int64_t)k * NB + tid2] = yacc;
-    }
-    __syncthreads();
-  }
-  double part[4][4];
-#pragma unroll
-  for (int m = 0; m < 4; m++)
-#pragma unroll
-    for (int g = 0; g < 4; g++) part[m][g] = 0;
-#pragma unroll
-  for (int n = 0; n < 4; n++) {
-    const int col = wc + 16 * n + (lane & 15);
-    const double inv_d = 1.0 / D_k[col];
-    const double wcol = FWD ? ysh[col] * inv_d : 0.0;
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int row = wr + 16 * m + mfma_row(lane, g);
-        const double xv = acc[m][n][g];
-        Vi[row * NB + col] = xv;
-        Sik[row * NB + col] = xv * inv_d;
-        if (FWD) part[m][g] += xv * wcol;
-      }
-  }
-  if (FWD) {
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        double v = part[m][g];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        if ((lane & 15) == 0) red[(wv & 1) * NB + wr + 16 * m + mfma_row(lane, g)] = v;
-      }
-    __syncthreads();
-    if (tid2 < NB) b[(int64_t)i * NB + tid2] -= red[tid2] + red[NB + tid2];
-  }
-}
-
 // ---- row-split panel kernels (latency path) ----------------------------------------------------------------------------
 // The panel solve and the one-column update have only (nt-k-1) tiles of work: one workgroup per tile leaves most CUs
 // idle and takes a full 128x128x128 product (27-33 us) on the critical path of every panel.  Here a workgroup owns
@@ -603,10 +537,9 @@ __global__ __launch_bounds__(256) void k_ldl_pair2_rs(double *__restrict__ S, co
   }
 }
 
-// Trailing updates.  MODE 0 (column): S_{i,k+1} -= V0_i L_{k+1,k}'  for i = k+1+blockIdx.x  (one panel, K = 128).
-// MODE 1 (pair):  S_ij -= V0_i L_jk' + V1_i L_{j,k+1}'  for the lower-triangular tile pairs base <= j <= i (K = 256): the
-// trailing matrix is read and written once per TWO panels, which halves its HBM traffic per flop.
-// MODE 2 (pair, the two tile columns base and base+1 only): what the next two panels need first (look-ahead).
+// Bulk trailing update, two panels per pass:  S_ij -= V0_i L_jk' + V1_i L_{j,k+1}'  for the lower-triangular tile pairs
+// base <= j <= i (K = 256): the trailing matrix is read and written once per TWO panels, which halves its HBM traffic per
+// flop.  (MODE is kept as a template parameter for the micro-benchmark variants; only MODE 1 exists.)
 // DBG (micro-benchmark only, ba_debug_update_bench): bit 0 = store instead of read-modify-write, bit 1 = every
 // workgroup reads the same operand tiles (L2-resident operands), bit 3 = workgroup-shared LDS staging with barriers
 // (the first version: 52.6 TFLOP/s against 59.8 for the wave-private staging that ships).
@@ -614,23 +547,11 @@ template <int MODE, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, const double *__restrict__ V0,
                                                         const double *__restrict__ V1, int k, int base, int nt,
                                                         int nblk) {
+  static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
   extern __shared__ double lds[];
   double *sA = lds, *sB = lds + NB * LDK;
   int i, j;
-  if (MODE == 0) {
-    i = k + 1 + blockIdx.x;
-    j = k + 1;
-  } else if (MODE == 2) {
-    const int m = nt - base;  // tiles in column base; column base+1 has m-1
-    const int t = blockIdx.x;
-    if (t < m) {
-      i = base + t;
-      j = base;
-    } else {
-      i = base + 1 + (t - m);
-      j = base + 1;
-    }
-  } else {
+  {
     // chunked block -> XCD map: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous
     // range of tile rows so that V_i stays in its L2 (speed only)
     const int per = (nblk + 7) / 8;
@@ -650,9 +571,7 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, c
 #pragma unroll
     for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
   const int io = (DBG & 2) ? base : i, jo = (DBG & 2) ? base : j;
-  if (MODE == 0)
-    tile_gemm_abt<1>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, nullptr, nullptr, sA, sB, acc);
-  else if (!(DBG & 8))
+  if (!(DBG & 8))
     tile_gemm_abt_priv<2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
                           S + tile_index(jo, k + 1) * NB * NB, lds, acc);
   else
@@ -768,16 +687,8 @@ static int set_kernel_attrs() {
   if (g_attr_done) return BA_OK;
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_diag),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_trsm<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSM_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_trsm<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSM_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_PRIV_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_PRIV_LDS));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 2>),

@@ -223,11 +223,6 @@ __device__ inline void jac_block(const T X[3], const T C[9], T J[24]) {
 #endif
 constexpr int NBW = BA_NBW;
 
-template <typename V, typename T>
-__device__ inline void stream_store16(T *p, V w) {
-  static_assert(sizeof(V) == 16, "16-byte store");
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
-}
 constexpr int CPAD = 16;  // camera rows are re-laid out to 16 elements (one 128-byte line for double) before the launch
 
 // x's camera block (9 per camera, 8-byte aligned rows) -> padded, 16-byte aligned rows.  Why: a lane fetching its camera
@@ -311,13 +306,14 @@ __global__ __launch_bounds__(BLK) void k_jac_coord(int64_t nobs, int64_t npnts, 
           const int ee = e + r, oo = ee / 24;
           v[r] = ws[oo * 25 + (ee - oo * 24)];
         }
-        // write-through store that does NOT keep the line in the XCD's L2 (sc1): 960 MB of Jacobian streaming through
-        // the 4 MB L2s would otherwise keep evicting the camera table every lane gathers from
         typedef T vst __attribute__((ext_vector_type(VEC)));
         vst w;
 #pragma unroll
         for (int r = 0; r < VEC; r++) w[r] = v[r];
-        stream_store16(out + e, w);
+        // plain 16-byte store.  (An inline-asm `global_store_dwordx4 ... sc1` was tried to keep the stream out of L2: no
+        // speed-up, and without the wait state hipcc inserts after a >64-bit store whose data registers are rewritten it
+        // corrupted 0.5 % of the blocks at 12 M observations -- found by tools/dbg_big.py, hence the plain store.)
+        *reinterpret_cast<vst *>(out + e) = w;
       }
     }
     __builtin_amdgcn_wave_barrier();

@@ -186,10 +186,11 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
                                                        double *__restrict__ S) {
   __shared__ double stage[BLK / 64][2][48];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t key = (int64_t)blockIdx.x * (BLK / 64) + wv;
-  if (key >= nkeys) return;
-  const int ca = key_ca[key], cb = key_cb[key];
   const int fr = lane & 15, fk = lane >> 4, tl = fk >> 1, al = fk & 1;
+  // grid-stride over the keys: the AQL grid size is a 32-bit count of work-items, and Final-13682 has 93.6 M keys
+  // (x 64 lanes > 2^32): a one-wave-per-key launch silently dropped the tail (zero pivots at the first lost diagonal).
+  for (int64_t key = (int64_t)blockIdx.x * (BLK / 64) + wv; key < nkeys; key += (int64_t)gridDim.x * (BLK / 64)) {
+  const int ca = key_ca[key], cb = key_cb[key];
   const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
   // element `lane` (< 48) of a task record: J_a[0..23] | J_b camera rows (2 x 9) | Y_b[0..5]
   const int e = lane;
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
       }
     }
   }
+  }  // key loop
 }
 
 // Column scaling of the reduced camera system (normalize = :J / :A, reference: src/lma_aux.jl:102-154): the reference
@@ -434,9 +436,12 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
   BA_HIP_CHECK(hipMemsetAsync(d_S, 0, (size_t)dense_ldl_tiles_doubles(n) * sizeof(double), st));
   if (p->nobs > 0)
     hipLaunchKernelGGL(k_obs_y, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->pnt0, d_J, d_Uinv, d_Y);
-  if (T->nkeys > 0)
-    hipLaunchKernelGGL(k_schur_blocks, dim3(grid_for(T->nkeys, BLK / 64)), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
+  if (T->nkeys > 0) {
+    int64_t nb = (T->nkeys + BLK / 64 - 1) / (BLK / 64);
+    if (nb > (int64_t)1 << 22) nb = (int64_t)1 << 22;  // 2^22 blocks x 256 lanes = 2^30 work-items
+    hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nb), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
                        T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_S);
+  }
   if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;

@@ -16,6 +16,7 @@ All arrays at this level are the reference's: 1-based int64 indices, x = [points
 INTEGRATION.md would; both are thin argument marshalling over the same C entry points.
 """
 import ctypes as C
+import sys
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -94,7 +95,6 @@ class BALNLPModel:
             self._h = C.c_void_p()
 
     def __del__(self):
-        import sys
         if sys is None or sys.is_finalizing():  # at interpreter exit the HIP context may already be gone: leak instead
             return
         try:

@@ -246,6 +246,26 @@ def test_lm_linesearch_vs_oracle(ba, orc, small_prob, gpu_ok):
     m.close()
 
 
+def test_many_cameras_step(ba, orc, gpu_ok):
+    """Wide reduced camera system (600 cameras -> n = 5400, 43 tile rows) with few points: exercises the tile indexing
+    of the Schur scatter, the paired-panel factorisation and the sweeps well beyond the other tests' sizes.  Reference:
+    dense normal equations assembled from the oracle's Jacobian and solved by numpy."""
+    p = ba.synthetic.make_problem(600, 500, 1800, seed=3)
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    lam = 50.0
+    d, half, jtr = ba.lm_step(m, p["x0"], lam)
+    rows, cols = orc.jac_structure(p["cam_idx1"], p["pnt_idx1"], p["npnts"])
+    vals = orc.jac_coord(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["npnts"])
+    r = orc.residuals(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["pt2d"], p["npnts"])
+    nvar = m.meta.nvar
+    J = np.zeros((2 * p["nobs"], nvar))
+    J[rows - 1, cols - 1] = vals
+    d_ref = np.linalg.solve(J.T @ J + lam * np.eye(nvar), -J.T @ r)
+    assert np.linalg.norm(d - d_ref) <= 1e-9 * np.linalg.norm(d_ref)
+    assert abs(half - 0.5 * np.sum((J @ d_ref + r) ** 2)) <= 1e-9 * half
+    m.close()
+
+
 def test_reader_to_model(ba, orc, small_prob, tmp_path, gpu_ok):
     p = small_prob
     path = str(tmp_path / "Synth" / "problem-12-400-pre.txt.bz2")
@@ -254,6 +274,22 @@ def test_reader_to_model(ba, orc, small_prob, tmp_path, gpu_ok):
     assert (m.ncams, m.npnts, m.nobs) == (p["ncams"], p["npnts"], p["nobs"])
     assert np.array_equal(m.meta.x0, p["x0"]) and np.array_equal(m.pt2d, p["pt2d"])
     r = m.cons(m.meta.x0)
+    r_ref = orc.residuals(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["pt2d"], p["npnts"])
+    assert np.all(np.abs(r - r_ref) <= _res_tol(r_ref, p["pt2d"], _focal(p["x0"], p["cam_idx1"], p["npnts"])))
+    m.close()
+
+
+def test_jacobian_vs_oracle_two_million_observations(ba, orc, gpu_ok):
+    """Every block of a 2 M-observation Jacobian against the oracle: catches sporadic corruption that a few thousand
+    observations do not (an inline-asm store without its hazard wait state once corrupted 0.5 % of the blocks, only
+    visible from ~10^6 observations up)."""
+    p = ba.synthetic.make_problem(400, 400000, 2000000, seed=21)
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    v = m.jac_coord(p["x0"]).reshape(-1, 24)
+    v_ref = orc.jac_coord(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["npnts"]).reshape(-1, 24)
+    rel = np.abs(v - v_ref).max(1) / np.abs(v_ref).max(1)
+    assert rel.max() <= 1e-12, (rel.max(), int((rel > 1e-12).sum()))
+    r = m.cons(p["x0"])
     r_ref = orc.residuals(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["pt2d"], p["npnts"])
     assert np.all(np.abs(r - r_ref) <= _res_tol(r_ref, p["pt2d"], _focal(p["x0"], p["cam_idx1"], p["npnts"])))
     m.close()
