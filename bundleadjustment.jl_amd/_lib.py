@@ -52,7 +52,7 @@ SYMBOLS = [
     "ba_jac_structure", "ba_jac_coord", "ba_jac_coord_f32", "ba_jtr", "ba_residual_dev", "ba_residual_f32_dev",
     "ba_jac_structure_dev", "ba_jac_coord_dev", "ba_jac_coord_f32_dev", "ba_jtr_dev", "ba_dev_malloc", "ba_dev_free",
     "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_synchronize", "ba_lm_solve", "ba_lm_reduce_doubles", "ba_lm_set_comm",
-    "ba_lm_step", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve",
+    "ba_lm_step", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
 ]
 
 _lib = None
@@ -97,6 +97,7 @@ def lib():
     L.ba_profile_reset.argtypes = [vp]
     L.ba_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(f64), C.POINTER(i64), C.POINTER(C.c_int)]
     L.ba_dense_ldl_solve.argtypes = [C.c_int, i64, vp, vp, vp, C.POINTER(f64)]
+    L.ba_dense_ldl_solve_f32.argtypes = [C.c_int, i64, vp, vp, vp, C.POINTER(f64)]
     _lib = L
     return L
 
@@ -124,12 +125,13 @@ def device_count():
     return n.value if rc == BA_OK else 0
 
 
-def dense_ldl_solve(A, b, device=0):
-    """Solve A x = b with the device blocked LDL' (A symmetric, only its lower triangle is read)."""
+def dense_ldl_solve(A, b, device=0, f32=False):
+    """Solve A x = b with the device blocked LDL' (A symmetric, only its lower triangle is read); f32: in Float32."""
     A = np.ascontiguousarray(A, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     n = A.shape[0]
     x = np.zeros(n)
     ms = C.c_double(0)
-    check(lib().ba_dense_ldl_solve(device, n, ptr(A), ptr(b), ptr(x), C.byref(ms)))
+    fn = lib().ba_dense_ldl_solve_f32 if f32 else lib().ba_dense_ldl_solve
+    check(fn(device, n, ptr(A), ptr(b), ptr(x), C.byref(ms)))
     return x, ms.value

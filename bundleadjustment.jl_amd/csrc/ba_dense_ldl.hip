@@ -22,17 +22,32 @@
 
 namespace {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d2 __attribute__((ext_vector_type(2)));
+// scalar-type traits: the f64 and f32 forms of the 16x16x4 MFMA share the A/B operand lane map
+// (A[i = l & 15][k = l >> 4]) but not the C/D map (f64: row = (l >> 4) + 4 reg; f32: row = 4 (l >> 4) + reg).
+template <typename T>
+struct RT;
+template <>
+struct RT<double> {
+  typedef double v4 __attribute__((ext_vector_type(4)));
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  static __device__ inline v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ inline int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <>
+struct RT<float> {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  static __device__ inline v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ inline int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+#define BA_VT typedef typename RT<T>::v4 d4; typedef typename RT<T>::v2 d2;
 
 constexpr int KC = 16;       // K chunk of the GEMM kernels staged through LDS
 constexpr int LDK = KC + 2;  // row stride 36 dwords: 36i+2k hit distinct banks for the MFMA operand reads
 constexpr int DBUF = 0;  // 1: two LDS chunk buffers + one barrier per chunk; 0: one buffer + two barriers (measured faster:
                          // 54.4 vs 52.3 TFLOP/s on the pair update, the barrier is not the limiter and 2x LDS costs occupancy slack)
-constexpr size_t GEMM_LDS = (size_t)(DBUF ? 2 : 1) * 2 * NB * LDK * sizeof(double);
+constexpr size_t GEMM_LDS_ELEMS = (size_t)(DBUF ? 2 : 1) * 2 * NB * LDK;
 
-// v_mfma_f64_16x16x4_f64 C/D layout: lane l, result register g hold C[row][l & 15]
-__device__ inline int mfma_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 
 // ---- diagonal tile ---------------------------------------------------------------------------------------------
 // One workgroup (4 waves) factors the 128x128 tile in LDS as 8x8 blocks of 16x16:
@@ -42,12 +57,15 @@ __device__ inline int mfma_row(int lane, int reg) { return (lane >> 4) + 4 * reg
 // upper triangle of the LDS image.  Writes L (scaled, D on the diagonal) back in place, Linv and D.
 constexpr int LDA2 = 130;  // row stride 260 dwords = 4 mod 64: conflict-free MFMA operand reads
 constexpr int XDL = 18;
-constexpr size_t DIAG_LDS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB + 16 * 17) * sizeof(double);
+constexpr size_t DIAG_LDS_ELEMS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB + 16 * 17);
 
-__global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, double *__restrict__ Linv_k,
-                                                   double *__restrict__ D_k, int *__restrict__ flag,
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__restrict__ Linv_k,
+                                                   T *__restrict__ D_k, int *__restrict__ flag,
                                                    unsigned long long *__restrict__ stamps) {
-  extern __shared__ double sm[];
+  BA_VT
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *sm = reinterpret_cast<T *>(smraw);
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;  // diagnostic phase timers (stamps != null only)
 #define STAMP(slot)                                        \
   if (stamps) {                                            \
@@ -56,7 +74,7 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
     tlast = tnow;                                          \
   }
   if (stamps) tlast = __builtin_amdgcn_s_memtime();
-  double *a = sm, *xd = sm + NB * LDA2, *dd = xd + 8 * 16 * XDL, *dinv = dd + NB, *l16 = dinv + NB;
+  T *a = sm, *xd = sm + NB * LDA2, *dd = xd + 8 * 16 * XDL, *dinv = dd + NB, *l16 = dinv + NB;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   // tile -> LDS: 16-byte loads, 8 in flight per thread; the strict upper triangle is zeroed
@@ -83,8 +101,8 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
        // workgroup barriers measured 40 us SLOWER per tile: the LDS round trips of one wave serialise)
       const int i = tid >> 4, c = tid & 15;
       for (int j = 0; j < 16; j++) {
-        const double d = a[(o + j) * LDA2 + o + j];
-        const double inv = 1.0 / d;
+        const T d = a[(o + j) * LDA2 + o + j];
+        const T inv = (T)1 / d;
         if (i > j && c > j && c <= i) a[(o + i) * LDA2 + o + c] -= a[(o + i) * LDA2 + o + j] * inv * a[(o + c) * LDA2 + o + j];
         if (tid == 0) {
           dd[o + j] = d;
@@ -105,10 +123,10 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
     __syncthreads();
     if (tid < NB - o - 16) {
       const int r = o + 16 + tid;
-      double xr[16];
+      T xr[16];
 #pragma unroll
       for (int c = 0; c < 16; c++) {
-        double sacc = a[r * LDA2 + o + c];
+        T sacc = a[r * LDA2 + o + c];
 #pragma unroll
         for (int m = 0; m < c; m++) sacc -= xr[m] * l16[c * 17 + m];
         xr[c] = sacc;
@@ -127,29 +145,28 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
       const int I = jb + 1 + ii, J = jb + 1 + jj;
       d4 acc;
 #pragma unroll
-      for (int g = 0; g < 4; g++) acc[g] = a[(16 * I + mfma_row(lane, g)) * LDA2 + 16 * J + fr];
+      for (int g = 0; g < 4; g++) acc[g] = a[(16 * I + RT<T>::row(lane, g)) * LDA2 + 16 * J + fr];
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         const int k = o + 4 * kk + fk;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[(16 * I + fr) * LDA2 + k], a[(16 * J + fr) * LDA2 + k] * dinv[k], acc, 0, 0,
-                                                   0);
+        acc = RT<T>::mfma(-a[(16 * I + fr) * LDA2 + k], a[(16 * J + fr) * LDA2 + k] * dinv[k], acc);
       }
 #pragma unroll
-      for (int g = 0; g < 4; g++) a[(16 * I + mfma_row(lane, g)) * LDA2 + 16 * J + fr] = acc[g];
+      for (int g = 0; g < 4; g++) a[(16 * I + RT<T>::row(lane, g)) * LDA2 + 16 * J + fr] = acc[g];
     }
     __syncthreads();
     STAMP(3)
   }
   if (tid < 128) {  // the eight 16x16 unit-lower inverses, one column per thread: l[i][m] = a[i][m] * dinv[m]
     const int o = 16 * (tid >> 4), c = tid & 15;
-    double *xj = xd + (tid >> 4) * 16 * XDL;
-    double yv[16];  // yv[m] = dinv[m] * x[m]
+    T *xj = xd + (tid >> 4) * 16 * XDL;
+    T yv[16];  // yv[m] = dinv[m] * x[m]
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-      double sacc = 0;
+      T sacc = 0;
 #pragma unroll
       for (int m = 0; m < i; m++) sacc += a[(o + i) * LDA2 + o + m] * yv[m];
-      const double xv = (i < c) ? 0.0 : (i == c ? 1.0 : -sacc);
+      const T xv = (i < c) ? 0.0 : (i == c ? 1.0 : -sacc);
       yv[i] = xv * dinv[o + i];
       xj[i * XDL + c] = xv;
     }
@@ -163,17 +180,17 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
           const int k = 16 * K + 4 * kk + fk;
-          const double af = a[(16 * I + fr) * LDA2 + k] * dinv[k];
-          const double bf = (K == J) ? xd[(J * 16 + 4 * kk + fk) * XDL + fr] : a[(16 * J + fr) * LDA2 + k];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+          const T af = a[(16 * I + fr) * LDA2 + k] * dinv[k];
+          const T bf = (K == J) ? xd[(J * 16 + 4 * kk + fk) * XDL + fr] : a[(16 * J + fr) * LDA2 + k];
+          acc = RT<T>::mfma(af, bf, acc);
         }
       }
       d4 out = {0, 0, 0, 0};
 #pragma unroll
       for (int g = 0; g < 4; g++)
-        out = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[(I * 16 + fr) * XDL + 4 * g + fk], acc[g], out, 0, 0, 0);
+        out = RT<T>::mfma(xd[(I * 16 + fr) * XDL + RT<T>::row(lane, g)], acc[g], out);
 #pragma unroll
-      for (int g = 0; g < 4; g++) a[(16 * J + fr) * LDA2 + 16 * I + mfma_row(lane, g)] = -out[g];
+      for (int g = 0; g < 4; g++) a[(16 * J + fr) * LDA2 + 16 * I + RT<T>::row(lane, g)] = -out[g];
     }
     __syncthreads();
   }
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
 #pragma unroll
     for (int e = 0; e < 2; e++) {
       const int c = c0 + e;
-      double l, x;
+      T l, x;
       if (c < i) {
         l = a[i * LDA2 + c] * dinv[c];
         x = ((i >> 4) == (c >> 4)) ? xd[((i >> 4) * 16 + (i & 15)) * XDL + (c & 15)] : a[c * LDA2 + i];
@@ -216,10 +233,11 @@ __global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ Skk, doub
 // workgroups per CU cover each other's barriers.
 // YACC (forward substitution fused into the panel solve): threads 0..127 also accumulate yacc = sum_k B0[tid][k] bk[k]
 // from the B chunks as they pass through LDS.
-template <int NP, bool YACC = false>
-__device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double *__restrict__ B0,
-                                     const double *__restrict__ A1, const double *__restrict__ B1, double *sA, double *sB,
-                                     d4 acc[4][4], const double *__restrict__ bk = nullptr, double *yacc = nullptr) {
+template <typename T, int NP, bool YACC = false>
+__device__ inline void tile_gemm_abt(const T *__restrict__ A0, const T *__restrict__ B0,
+                                     const T *__restrict__ A1, const T *__restrict__ B1, T *sA, T *sB,
+                                     typename RT<T>::v4 acc[4][4], const T *__restrict__ bk = nullptr, T *yacc = nullptr) {
+  BA_VT
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
   const int fr = lane & 15, fk = lane >> 4;
@@ -253,9 +271,9 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
     // DBUF: buffer ch&1 is complete and everybody has finished reading the other one.  Single buffer: everybody has
     // finished reading the previous chunk.
     __syncthreads();
-    double *cA = sA + (ch & 1) * BUF, *cB = sB + (ch & 1) * BUF;
+    T *cA = sA + (ch & 1) * BUF, *cB = sB + (ch & 1) * BUF;
     if (DBUF ? (ch + 1 < NCH) : true) {  // registers -> LDS (DBUF: chunk ch+1 into the other buffer, overlapping the MFMAs)
-      double *nA = sA + ((ch + 1) & 1) * BUF, *nB = sB + ((ch + 1) & 1) * BUF;
+      T *nA = sA + ((ch + 1) & 1) * BUF, *nB = sB + ((ch + 1) & 1) * BUF;
 #pragma unroll
       for (int it = 0; it < NLD; it++) {
         *reinterpret_cast<d2 *>(nA + (lrow + RPS * it) * LDK + 2 * lc2) = pa[it];
@@ -265,8 +283,8 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
     if (!DBUF) __syncthreads();
     const int nx = ch + (DBUF ? 2 : 1);
     if (nx < NCH) {  // next chunk -> registers, in flight while this chunk is multiplied
-      const double *A = (NP == 2 && nx >= NB / KC) ? A1 : A0;
-      const double *B = (NP == 2 && nx >= NB / KC) ? B1 : B0;
+      const T *A = (NP == 2 && nx >= NB / KC) ? A1 : A0;
+      const T *B = (NP == 2 && nx >= NB / KC) ? B1 : B0;
       const int k0 = (nx & (NB / KC - 1)) * KC;
 #pragma unroll
       for (int it = 0; it < NLD; it++) {
@@ -276,7 +294,7 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
     }
     if (YACC) {
       if (tid < NB) {
-        double ya = *yacc;
+        T ya = *yacc;
 #pragma unroll
         for (int q = 0; q < KC; q++) ya += cB[tid * LDK + q] * bk[ch * KC + q];
         *yacc = ya;
@@ -284,7 +302,7 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
     }
 #pragma unroll
     for (int kk = 0; kk < KC / 4; kk++) {
-      double af[4], bf[4];
+      T af[4], bf[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) af[m] = cA[(wr + 16 * m + fr) * LDK + kk * 4 + fk];
 #pragma unroll
@@ -292,7 +310,7 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < 4; n++) acc[m][n] = RT<T>::mfma(af[m], bf[n], acc[m][n]);
     }
   }
 }
@@ -300,21 +318,22 @@ __device__ inline void tile_gemm_abt(const double *__restrict__ A0, const double
 // Wave-private variant: every wave stages the 64 A rows and 64 B rows IT needs in its own LDS region, so the K loop has
 // no workgroup barrier at all (each operand slice is loaded by the two waves that use it: 2x the L2->LDS traffic, which
 // is not the limiter).  LDS: 4 waves x 128 rows x 18 doubles = 73.7 KB.
-constexpr size_t GEMM_PRIV_LDS = (size_t)4 * 2 * 64 * LDK * sizeof(double);
-template <int NP>
-__device__ inline void tile_gemm_abt_priv(const double *__restrict__ A0, const double *__restrict__ B0,
-                                          const double *__restrict__ A1, const double *__restrict__ B1, double *lds,
-                                          d4 acc[4][4]) {
+constexpr size_t GEMM_PRIV_LDS_ELEMS = (size_t)4 * 2 * 64 * LDK;
+template <typename T, int NP>
+__device__ inline void tile_gemm_abt_priv(const T *__restrict__ A0, const T *__restrict__ B0,
+                                          const T *__restrict__ A1, const T *__restrict__ B1, T *lds,
+                                          typename RT<T>::v4 acc[4][4]) {
+  BA_VT
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
   const int fr = lane & 15, fk = lane >> 4;
-  double *sA = lds + wv * (2 * 64 * LDK), *sB = sA + 64 * LDK;
+  T *sA = lds + wv * (2 * 64 * LDK), *sB = sA + 64 * LDK;
   constexpr int UPR = KC / 2;       // 16-byte units per row of a chunk (8)
   constexpr int RPS = 64 / UPR;     // rows per step of the 64 lanes (8)
   constexpr int NLD = 64 / RPS;     // steps to cover 64 rows (8)
   const int lrow = lane / UPR, lc2 = lane % UPR;
   d2 pa[NLD], pb[NLD];
-  const double *Ab = A0 + wr * NB, *Bb = B0 + wc * NB;
+  const T *Ab = A0 + wr * NB, *Bb = B0 + wc * NB;
 #pragma unroll
   for (int it = 0; it < NLD; it++) {
     pa[it] = *reinterpret_cast<const d2 *>(Ab + (lrow + RPS * it) * NB + 2 * lc2);
@@ -333,8 +352,8 @@ __device__ inline void tile_gemm_abt_priv(const double *__restrict__ A0, const d
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nx = ch + 1;
     if (nx < NCH) {
-      const double *A = ((NP == 2 && nx >= NB / KC) ? A1 : A0) + wr * NB;
-      const double *B = ((NP == 2 && nx >= NB / KC) ? B1 : B0) + wc * NB;
+      const T *A = ((NP == 2 && nx >= NB / KC) ? A1 : A0) + wr * NB;
+      const T *B = ((NP == 2 && nx >= NB / KC) ? B1 : B0) + wc * NB;
       const int k0 = (nx & (NB / KC - 1)) * KC;
 #pragma unroll
       for (int it = 0; it < NLD; it++) {
@@ -344,7 +363,7 @@ __device__ inline void tile_gemm_abt_priv(const double *__restrict__ A0, const d
     }
 #pragma unroll
     for (int kk = 0; kk < KC / 4; kk++) {
-      double af[4], bf[4];
+      T af[4], bf[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * LDK + kk * 4 + fk];
 #pragma unroll
@@ -352,7 +371,7 @@ __device__ inline void tile_gemm_abt_priv(const double *__restrict__ A0, const d
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < 4; n++) acc[m][n] = RT<T>::mfma(af[m], bf[n], acc[m][n]);
     }
   }
 }
@@ -363,12 +382,13 @@ __device__ inline void tile_gemm_abt_priv(const double *__restrict__ A0, const d
 // RS = 32 rows of a tile (4 waves x (32 rows x 32 columns) = 2x2 MFMA blocks each), so 4x as many workgroups run
 // concurrently and each is ~4x shorter.
 constexpr int RS = 32;
-constexpr size_t RS_LDS = (size_t)((RS + NB) * LDK + 5 * NB) * sizeof(double);
+constexpr size_t RS_LDS_ELEMS = (size_t)((RS + NB) * LDK + 5 * NB);
 
-template <bool YACC, int NP = 1>
-__device__ inline void tile_gemm_rows(const double *__restrict__ A, const double *__restrict__ B, double *sA, double *sB,
-                                      d4 acc[2][2], const double *__restrict__ bk, double *yacc,
-                                      const double *__restrict__ A1 = nullptr, const double *__restrict__ B1 = nullptr) {
+template <typename T, bool YACC, int NP = 1>
+__device__ inline void tile_gemm_rows(const T *__restrict__ A, const T *__restrict__ B, T *sA, T *sB,
+                                      typename RT<T>::v4 acc[2][2], const T *__restrict__ bk, T *yacc,
+                                      const T *__restrict__ A1 = nullptr, const T *__restrict__ B1 = nullptr) {
+  BA_VT
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wc = wv * 32;
   const int fr = lane & 15, fk = lane >> 4;
@@ -387,8 +407,8 @@ __device__ inline void tile_gemm_rows(const double *__restrict__ A, const double
     __syncthreads();
     if (ch + 1 < NCH) {
       const int nx = ch + 1;
-      const double *An = (NP == 2 && nx >= NB / KC) ? A1 : A;
-      const double *Bn = (NP == 2 && nx >= NB / KC) ? B1 : B;
+      const T *An = (NP == 2 && nx >= NB / KC) ? A1 : A;
+      const T *Bn = (NP == 2 && nx >= NB / KC) ? B1 : B;
       const int k0 = (nx & (NB / KC - 1)) * KC;
       pa = *reinterpret_cast<const d2 *>(An + lrow * NB + k0 + 2 * lc2);
 #pragma unroll
@@ -396,7 +416,7 @@ __device__ inline void tile_gemm_rows(const double *__restrict__ A, const double
     }
     if (YACC) {
       if (tid < NB) {
-        double ya = *yacc;
+        T ya = *yacc;
 #pragma unroll
         for (int q = 0; q < KC; q++) ya += sB[tid * LDK + q] * bk[ch * KC + q];
         *yacc = ya;
@@ -404,7 +424,7 @@ __device__ inline void tile_gemm_rows(const double *__restrict__ A, const double
     }
 #pragma unroll
     for (int kk = 0; kk < KC / 4; kk++) {
-      double af[2], bf[2];
+      T af[2], bf[2];
 #pragma unroll
       for (int m = 0; m < 2; m++) af[m] = sA[(16 * m + fr) * LDK + kk * 4 + fk];
 #pragma unroll
@@ -412,29 +432,31 @@ __device__ inline void tile_gemm_rows(const double *__restrict__ A, const double
 #pragma unroll
       for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < 2; n++) acc[m][n] = RT<T>::mfma(af[m], bf[n], acc[m][n]);
     }
   }
 }
 
 // rows [32 rq, 32 rq + 32) of X_i = S_ik Linv_k' -> V_i, S_ik = X_i D_k^-1; FWD: y_k and b_i -= L_ik y_k ride along.
 // grid = 4 (nt-k-1): i = k + 1 + blockIdx.x / 4, rq = blockIdx.x % 4
-template <bool FWD>
-__global__ __launch_bounds__(256) void k_ldl_trsm_rs(double *__restrict__ S, const double *__restrict__ Linv_k,
-                                                      const double *__restrict__ D_k, double *__restrict__ V, int k,
-                                                      double *__restrict__ b, double *__restrict__ y) {
-  extern __shared__ double lds[];
-  double *sA = lds, *sB = lds + RS * LDK, *ysh = lds + (RS + NB) * LDK, *red = ysh + NB;  // red: 4 x 32
+template <typename T, bool FWD>
+__global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const T *__restrict__ Linv_k,
+                                                      const T *__restrict__ D_k, T *__restrict__ V, int k,
+                                                      T *__restrict__ b, T *__restrict__ y) {
+  BA_VT
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  T *sA = lds, *sB = lds + RS * LDK, *ysh = lds + (RS + NB) * LDK, *red = ysh + NB;  // red: 4 x 32
   const int i = k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
-  double *Sik = S + tile_index(i, k) * NB * NB + r0 * NB;
-  double *Vi = V + (int64_t)i * NB * NB + r0 * NB;
-  d4 acc[2][2];
+  T *Sik = S + tile_index(i, k) * NB * NB + r0 * NB;
+  T *Vi = V + (int64_t)i * NB * NB + r0 * NB;
+  typename RT<T>::v4 acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
     for (int n = 0; n < 2; n++) acc[m][n] = (d4){0, 0, 0, 0};
-  double yacc = 0;
-  tile_gemm_rows<FWD>(Sik, Linv_k, sA, sB, acc, FWD ? b + (int64_t)k * NB : nullptr, &yacc);
+  T yacc = 0;
+  tile_gemm_rows<T, FWD>(Sik, Linv_k, sA, sB, acc, FWD ? b + (int64_t)k * NB : nullptr, &yacc);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wc = wv * 32;
   if (FWD) {
     if (tid < NB) {
@@ -443,7 +465,7 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(double *__restrict__ S, con
     }
     __syncthreads();
   }
-  double part[2][4];
+  T part[2][4];
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -451,14 +473,14 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(double *__restrict__ S, con
 #pragma unroll
   for (int n = 0; n < 2; n++) {
     const int col = wc + 16 * n + (lane & 15);
-    const double inv_d = 1.0 / D_k[col];
-    const double wcol = FWD ? ysh[col] * inv_d : 0.0;
+    const T inv_d = (T)1 / D_k[col];
+    const T wcol = FWD ? ysh[col] * inv_d : 0.0;
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const int row = 16 * m + mfma_row(lane, g);
-        const double xv = acc[m][n][g];
+        const int row = 16 * m + RT<T>::row(lane, g);
+        const T xv = acc[m][n][g];
         Vi[row * NB + col] = xv;
         Sik[row * NB + col] = xv * inv_d;
         if (FWD) part[m][g] += xv * wcol;
@@ -469,12 +491,12 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(double *__restrict__ S, con
     for (int m = 0; m < 2; m++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        double v = part[m][g];
+        T v = part[m][g];
         v += __shfl_xor(v, 1, 64);
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 4, 64);
         v += __shfl_xor(v, 8, 64);
-        if ((lane & 15) == 0) red[wv * RS + 16 * m + mfma_row(lane, g)] = v;
+        if ((lane & 15) == 0) red[wv * RS + 16 * m + RT<T>::row(lane, g)] = v;
       }
     __syncthreads();
     if (tid < RS) b[(int64_t)i * NB + r0 + tid] -= ((red[tid] + red[RS + tid]) + red[2 * RS + tid]) + red[3 * RS + tid];
@@ -482,18 +504,21 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(double *__restrict__ S, con
 }
 
 // rows [32 rq, 32 rq + 32) of S_{i,k+1} -= V0_i L_{k+1,k}'   (grid = 4 (nt-k-1))
-__global__ __launch_bounds__(256) void k_ldl_col_rs(double *__restrict__ S, const double *__restrict__ V0, int k) {
-  extern __shared__ double lds[];
-  double *sA = lds, *sB = lds + RS * LDK;
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const T *__restrict__ V0, int k) {
+  BA_VT
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  T *sA = lds, *sB = lds + RS * LDK;
   const int i = k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
-  d4 acc[2][2];
+  typename RT<T>::v4 acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
     for (int n = 0; n < 2; n++) acc[m][n] = (d4){0, 0, 0, 0};
-  tile_gemm_rows<false>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(k + 1, k) * NB * NB, sA, sB, acc, nullptr, nullptr);
+  tile_gemm_rows<T, false>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(k + 1, k) * NB * NB, sA, sB, acc, nullptr, nullptr);
   const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) * 32;
-  double *Sij = S + tile_index(i, k + 1) * NB * NB + r0 * NB;
+  T *Sij = S + tile_index(i, k + 1) * NB * NB + r0 * NB;
 #pragma unroll
   for (int n = 0; n < 2; n++) {
     const int col = wc + 16 * n + (lane & 15);
@@ -501,7 +526,7 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(double *__restrict__ S, cons
     for (int m = 0; m < 2; m++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const int row = 16 * m + mfma_row(lane, g);
+        const int row = 16 * m + RT<T>::row(lane, g);
         Sij[row * NB + col] -= acc[m][n][g];
       }
   }
@@ -509,21 +534,24 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(double *__restrict__ S, cons
 
 // rows [32 rq, 32 rq + 32) of S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' for the two tile columns j = base, base+1 (what the
 // next two panels need first).  grid = 4 (2m - 1), m = nt - base: tiles (base+t, base) for t < m, then (base+1+t', base+1)
-__global__ __launch_bounds__(256) void k_ldl_pair2_rs(double *__restrict__ S, const double *__restrict__ V0,
-                                                       const double *__restrict__ V1, int k, int base, int nt) {
-  extern __shared__ double lds[];
-  double *sA = lds, *sB = lds + RS * LDK;
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_pair2_rs(T *__restrict__ S, const T *__restrict__ V0,
+                                                       const T *__restrict__ V1, int k, int base, int nt) {
+  BA_VT
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  T *sA = lds, *sB = lds + RS * LDK;
   const int m = nt - base, t = blockIdx.x >> 2, r0 = (blockIdx.x & 3) * RS;
   const int i = t < m ? base + t : base + 1 + (t - m), j = t < m ? base : base + 1;
-  d4 acc[2][2];
+  typename RT<T>::v4 acc[2][2];
 #pragma unroll
   for (int mm = 0; mm < 2; mm++)
 #pragma unroll
     for (int n = 0; n < 2; n++) acc[mm][n] = (d4){0, 0, 0, 0};
-  tile_gemm_rows<false, 2>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(j, k) * NB * NB, sA, sB, acc, nullptr, nullptr,
+  tile_gemm_rows<T, false, 2>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(j, k) * NB * NB, sA, sB, acc, nullptr, nullptr,
                            V1 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(j, k + 1) * NB * NB);
   const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) * 32;
-  double *Sij = S + tile_index(i, j) * NB * NB + r0 * NB;
+  T *Sij = S + tile_index(i, j) * NB * NB + r0 * NB;
 #pragma unroll
   for (int n = 0; n < 2; n++) {
     const int col = wc + 16 * n + (lane & 15);
@@ -531,7 +559,7 @@ __global__ __launch_bounds__(256) void k_ldl_pair2_rs(double *__restrict__ S, co
     for (int mm = 0; mm < 2; mm++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const int row = 16 * mm + mfma_row(lane, g);
+        const int row = 16 * mm + RT<T>::row(lane, g);
         Sij[row * NB + col] -= acc[mm][n][g];
       }
   }
@@ -543,13 +571,15 @@ __global__ __launch_bounds__(256) void k_ldl_pair2_rs(double *__restrict__ S, co
 // DBG (micro-benchmark only, ba_debug_update_bench): bit 0 = store instead of read-modify-write, bit 1 = every
 // workgroup reads the same operand tiles (L2-resident operands), bit 3 = workgroup-shared LDS staging with barriers
 // (the first version: 52.6 TFLOP/s against 59.8 for the wave-private staging that ships).
-template <int MODE, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, const double *__restrict__ V0,
-                                                        const double *__restrict__ V1, int k, int base, int nt,
+template <typename T, int MODE, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const T *__restrict__ V0,
+                                                        const T *__restrict__ V1, int k, int base, int nt,
                                                         int nblk) {
+  BA_VT
   static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
-  extern __shared__ double lds[];
-  double *sA = lds, *sB = lds + NB * LDK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  T *sA = lds, *sB = lds + NB * LDK;
   int i, j;
   {
     // chunked block -> XCD map: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous
@@ -557,42 +587,42 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, c
     const int per = (nblk + 7) / 8;
     int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (t >= nblk) return;
-    int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    int ii = (int)((sqrt(8.0 * (T)t + 1.0) - 1.0) * 0.5);
     while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
     while (ii * (ii + 1) / 2 > t) ii--;
     const int jj = t - ii * (ii + 1) / 2;
     i = base + ii;
     j = base + jj;
   }
-  double *Sij = S + tile_index(i, j) * NB * NB;
-  d4 acc[4][4];
+  T *Sij = S + tile_index(i, j) * NB * NB;
+  typename RT<T>::v4 acc[4][4];
 #pragma unroll
   for (int m = 0; m < 4; m++)
 #pragma unroll
     for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
   const int io = (DBG & 2) ? base : i, jo = (DBG & 2) ? base : j;
   if (!(DBG & 8))
-    tile_gemm_abt_priv<2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+    tile_gemm_abt_priv<T, 2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
                           S + tile_index(jo, k + 1) * NB * NB, lds, acc);
   else
-    tile_gemm_abt<2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+    tile_gemm_abt<T, 2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
                      S + tile_index(jo, k + 1) * NB * NB, sA, sB, acc);
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
   const int lane = tid2 & 63, wv = tid2 >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
   // epilogue: the 64 values of a lane are read-modify-written in two batches of 32 so that 32 loads are in flight at once
-  double *cbase = Sij + (wr + (lane >> 4)) * NB + wc + (lane & 15);
+  T *cbase = Sij + wr * NB + wc + (lane & 15);
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    double cv[2][4][4];
+    T cv[2][4][4];
     if (!(DBG & 1)) {
 #pragma unroll
       for (int n2 = 0; n2 < 2; n2++)
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
-          for (int g = 0; g < 4; g++) cv[n2][m][g] = cbase[(16 * m + 4 * g) * NB + 16 * (2 * h + n2)];
+          for (int g = 0; g < 4; g++) cv[n2][m][g] = cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)];
     }
 #pragma unroll
     for (int n2 = 0; n2 < 2; n2++)
@@ -600,30 +630,33 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(double *__restrict__ S, c
       for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-          const double a = acc[m][2 * h + n2][g];
-          cbase[(16 * m + 4 * g) * NB + 16 * (2 * h + n2)] = (DBG & 1) ? a : cv[n2][m][g] - a;
+          const T a = acc[m][2 * h + n2][g];
+          cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)] = (DBG & 1) ? a : cv[n2][m][g] - a;
         }
   }
 }
 
 // ---- triangular solves -------------------------------------------------------------------------------------------------
-__device__ inline double wsum(double v) {
+template <typename T>
+__device__ inline T wsum(T v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
 // forward step k: y_k = Linv_k b_k (every workgroup recomputes it; block 0 stores it), then b_i -= L_ik y_k, i > k.
-__global__ __launch_bounds__(256) void k_fwd_step(const double *__restrict__ S, const double *__restrict__ Linv,
-                                                   double *__restrict__ b, double *__restrict__ y, int k) {
-  __shared__ double yk[NB];
+template <typename T>
+__global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const T *__restrict__ Linv,
+                                                   T *__restrict__ b, T *__restrict__ y, int k) {
+  BA_VT
+  __shared__ T yk[NB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const double *Lk = Linv + (int64_t)k * NB * NB;
-  const double2 bk = *reinterpret_cast<const double2 *>(b + (int64_t)k * NB + 2 * lane);
+  const T *Lk = Linv + (int64_t)k * NB * NB;
+  const d2 bk = *reinterpret_cast<const d2 *>(b + (int64_t)k * NB + 2 * lane);
   for (int rr = 0; rr < 32; rr++) {
     int row = wv * 32 + rr;
-    double2 l = *reinterpret_cast<const double2 *>(Lk + row * NB + 2 * lane);
-    double s = wsum(l.x * bk.x + l.y * bk.y);
+    d2 l = *reinterpret_cast<const d2 *>(Lk + row * NB + 2 * lane);
+    T s = wsum(l.x * bk.x + l.y * bk.y);
     if (lane == 0) yk[row] = s;
   }
   __syncthreads();
@@ -632,29 +665,31 @@ __global__ __launch_bounds__(256) void k_fwd_step(const double *__restrict__ S, 
     return;
   }
   const int i = k + blockIdx.x;
-  const double *Lik = S + tile_index(i, k) * NB * NB;
-  const double y0 = yk[2 * lane], y1 = yk[2 * lane + 1];
+  const T *Lik = S + tile_index(i, k) * NB * NB;
+  const T y0 = yk[2 * lane], y1 = yk[2 * lane + 1];
   for (int rr = 0; rr < 32; rr++) {
     int row = wv * 32 + rr;
-    double2 l = *reinterpret_cast<const double2 *>(Lik + row * NB + 2 * lane);
-    double s = wsum(l.x * y0 + l.y * y1);
+    d2 l = *reinterpret_cast<const d2 *>(Lik + row * NB + 2 * lane);
+    T s = wsum(l.x * y0 + l.y * y1);
     if (lane == 0) b[(int64_t)i * NB + row] -= s;
   }
 }
 
 // backward step k: x_k = Linv_k' z_k with z = y / D (every workgroup recomputes it; block 0 stores it into b_k),
 // then y_j -= D_j (L_kj' x_k) ... expressed on z: z_j -= L_kj' x_k, i.e. y_j -= D_j * (L_kj' x_k), j < k.
-__global__ __launch_bounds__(256) void k_bwd_step(const double *__restrict__ S, const double *__restrict__ Linv,
-                                                   const double *__restrict__ D, double *__restrict__ y,
-                                                   double *__restrict__ x, int k) {
-  __shared__ double zk[NB], xk[NB], part[2][NB];
+template <typename T>
+__global__ __launch_bounds__(256) void k_bwd_step(const T *__restrict__ S, const T *__restrict__ Linv,
+                                                   const T *__restrict__ D, T *__restrict__ y,
+                                                   T *__restrict__ x, int k) {
+  BA_VT
+  __shared__ T zk[NB], xk[NB], part[2][NB];
   const int tid = threadIdx.x;
   const int c = tid & (NB - 1), half = tid >> 7;
   if (tid < NB) zk[tid] = y[(int64_t)k * NB + tid] / D[(int64_t)k * NB + tid];
   __syncthreads();
   {
-    const double *Lk = Linv + (int64_t)k * NB * NB;
-    double s = 0;
+    const T *Lk = Linv + (int64_t)k * NB * NB;
+    T s = 0;
     for (int r = half * 64; r < half * 64 + 64; r++) s += Lk[r * NB + c] * zk[r];
     part[half][c] = s;
   }
@@ -666,8 +701,8 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double *__restrict__ S, 
     return;
   }
   const int j = blockIdx.x - 1;  // 0 .. k-1
-  const double *Lkj = S + tile_index(k, j) * NB * NB;
-  double s = 0;
+  const T *Lkj = S + tile_index(k, j) * NB * NB;
+  T s = 0;
   for (int r = half * 64; r < half * 64 + 64; r++) s += Lkj[r * NB + c] * xk[r];
   part[half][c] = s;
   __syncthreads();
@@ -682,26 +717,28 @@ int64_t dense_ldl_tiles_doubles(int64_t n_unpadded) {
   return nt * (nt + 1) / 2 * NB * NB;
 }
 
-static bool g_attr_done = false;
+template <typename T>
 static int set_kernel_attrs() {
+  static bool g_attr_done = false;
   if (g_attr_done) return BA_OK;
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_diag),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_PRIV_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_PRIV_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_PRIV_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 8>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<1, 9>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_diag<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 9>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
   g_attr_done = true;
   return BA_OK;
 }
 
-int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S) {
+template <typename T>
+int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S) {
   int64_t nt = (n_unpadded + NB - 1) / NB;
   if (nt < 1) nt = 1;
   w->n = nt * NB;
@@ -710,10 +747,10 @@ int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S) {
     w->S = external_S;
     w->own_S = false;
   } else {
-    BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)dense_ldl_tiles_doubles(n_unpadded) * sizeof(double)));
+    BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)dense_ldl_tiles_doubles(n_unpadded) * sizeof(T)));
     w->own_S = true;
   }
-  BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(double)));  // 2 x two panels of L*D
+  BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(T)));  // 2 x two panels of L*D
   {
     // Look-ahead needs the latency-bound panel chain to run BESIDE the bulk update.  Its GEMM-shaped kernels only need
     // workgroup slots as they free up, so they go to a HIGH-PRIORITY stream; the one-workgroup diagonal-tile kernel needs a
@@ -751,13 +788,14 @@ int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S) {
   }
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_chain, hipEventDisableTiming));
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_bulk, hipEventDisableTiming));
-  BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(double)));
-  BA_HIP_CHECK(hipMalloc((void **)&w->D, (size_t)nt * NB * 2 * sizeof(double)));  // D | y scratch
+  BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(T)));
+  BA_HIP_CHECK(hipMalloc((void **)&w->D, (size_t)nt * NB * 2 * sizeof(T)));  // D | y scratch
   BA_HIP_CHECK(hipMalloc((void **)&w->flag, sizeof(int)));
-  return set_kernel_attrs();
+  return set_kernel_attrs<T>();
 }
 
-void dense_ldl_free(DenseLDL *w) {
+template <typename T>
+void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->own_S && w->S) (void)hipFree(w->S);
   if (w->V) (void)hipFree(w->V);
   if (w->Linv) (void)hipFree(w->Linv);
@@ -767,55 +805,59 @@ void dense_ldl_free(DenseLDL *w) {
   if (w->bulk) (void)hipStreamDestroy(w->bulk);
   if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
   if (w->ev_bulk) (void)hipEventDestroy(w->ev_bulk);
-  *w = DenseLDL();
+  *w = DenseLDLT<T>();
 }
 
-static int launch_diag(ba_problem *p, DenseLDL *w, int k, hipStream_t st) {
+template <typename T>
+static int launch_diag(ba_problem *p, DenseLDLT<T> *w, int k, hipStream_t st) {
   ProfScope ps(p, PC_LDL_DIAG, st);
-  hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), DIAG_LDS, st, w->S + tile_index(k, k) * NB * NB,
+  hipLaunchKernelGGL(k_ldl_diag<T>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(T), st, w->S + tile_index(k, k) * NB * NB,
                      w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag, (unsigned long long *)nullptr);
   return BA_OK;
 }
 
 // b != null: forward substitution of b fused (y_k and b_i -= L_ik y_k); the last panel has no tile below it, its y_k
 // comes from the stand-alone forward step kernel.
-static int launch_trsm(ba_problem *p, DenseLDL *w, int k, double *V, double *b, hipStream_t st) {
+template <typename T>
+static int launch_trsm(ba_problem *p, DenseLDLT<T> *w, int k, T *V, T *b, hipStream_t st) {
   const int m = (int)w->nt - k - 1;
-  double *y = w->D + w->nt * NB;
+  T *y = w->D + w->nt * NB;
   if (m <= 0) {
-    if (b) hipLaunchKernelGGL(k_fwd_step, dim3(1), dim3(256), 0, st, w->S, w->Linv, b, y, k);
+    if (b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, st, w->S, w->Linv, b, y, k);
     return BA_OK;
   }
   ProfScope ps(p, PC_LDL_TRSM, st);
   if (b)
-    hipLaunchKernelGGL(k_ldl_trsm_rs<true>, dim3(4 * m), dim3(256), RS_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
+    hipLaunchKernelGGL((k_ldl_trsm_rs<T, true>), dim3(4 * m), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->Linv + (int64_t)k * NB * NB,
                        w->D + (int64_t)k * NB, V, k, b, y);
   else
-    hipLaunchKernelGGL(k_ldl_trsm_rs<false>, dim3(4 * m), dim3(256), RS_LDS, st, w->S, w->Linv + (int64_t)k * NB * NB,
+    hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * m), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->Linv + (int64_t)k * NB * NB,
                        w->D + (int64_t)k * NB, V, k, b, y);
   return BA_OK;
 }
 
-static int launch_col(ba_problem *p, DenseLDL *w, int k, const double *V0, hipStream_t st) {
+template <typename T>
+static int launch_col(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0, hipStream_t st) {
   const int m = (int)w->nt - k - 1;
   if (m <= 0) return BA_OK;
   ProfScope ps(p, PC_LDL_SYRK, st);
-  hipLaunchKernelGGL(k_ldl_col_rs, dim3(4 * m), dim3(256), RS_LDS, st, w->S, V0, k);
+  hipLaunchKernelGGL(k_ldl_col_rs<T>, dim3(4 * m), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, V0, k);
   return BA_OK;
 }
 
 // pair update of the tile columns >= base with panels k, k+1 (first2: only columns base and base+1)
-static int launch_pair(ba_problem *p, DenseLDL *w, int k, int base, bool first2, const double *V0, const double *V1,
+template <typename T>
+static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, bool first2, const T *V0, const T *V1,
                        hipStream_t st) {
   const int nt = (int)w->nt, m = nt - base;
   if (m <= 0) return BA_OK;
   ProfScope ps(p, PC_LDL_SYRK, st);
   if (first2) {
     const int nblk = m + (m > 1 ? m - 1 : 0);
-    hipLaunchKernelGGL(k_ldl_pair2_rs, dim3(4 * nblk), dim3(256), RS_LDS, st, w->S, V0, V1, k, base, nt);
+    hipLaunchKernelGGL(k_ldl_pair2_rs<T>, dim3(4 * nblk), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, V0, V1, k, base, nt);
   } else {
     const int nblk = m * (m + 1) / 2;
-    hipLaunchKernelGGL(k_ldl_update<1>, dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS, st, w->S, V0, V1, k, base, nt, nblk);
+    hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st, w->S, V0, V1, k, base, nt, nblk);
   }
   return BA_OK;
 }
@@ -825,10 +867,11 @@ static int launch_pair(ba_problem *p, DenseLDL *w, int k, int base, bool first2,
 // Look-ahead: the pair update is split into the two tile columns the NEXT panels need (side stream, followed by the next
 // diag/trsm/column/diag/trsm chain) and the rest (main stream), so the latency-bound chain hides behind the bulk GEMM.
 // With per-kernel profiling on, everything runs on one stream so that the event pairs time single kernels.
-int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot, double *d_b) {
+template <typename T>
+int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b) {
   const int nt = (int)w->nt;
   const int64_t panel = (int64_t)nt * NB * NB;
-  double *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
+  T *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
   BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
   // pairs whose bulk update is shorter than the panel chain gain nothing from giving CUs away: overlap only while
   // at least OVERLAP_MIN_TILES tile rows remain
@@ -851,7 +894,7 @@ int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot
     launch_trsm(p, w, 1, Vs[0][1], d_b, ss);
   }
   for (int k = 0, q = 0; k + 2 < nt; k += 2, q ^= 1) {
-    double *V0 = Vs[q][0], *V1 = Vs[q][1], *W0 = Vs[q ^ 1][0], *W1 = Vs[q ^ 1][1];
+    T *V0 = Vs[q][0], *V1 = Vs[q][1], *W0 = Vs[q ^ 1][0], *W1 = Vs[q ^ 1][1];
     if (forked && nt - k - 2 < OVERLAP_MIN_TILES) {  // join: the tail runs on the whole GPU, one stream
       BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));
       BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));
@@ -893,69 +936,70 @@ int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot
   return BA_OK;
 }
 
-int dense_ldl_solve(ba_problem *p, DenseLDL *w, double *d_b, hipStream_t st, bool forward_done) {
+template <typename T>
+int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool forward_done) {
   const int nt = (int)w->nt;
-  double *y = w->D + (int64_t)nt * NB;
+  T *y = w->D + (int64_t)nt * NB;
   ProfScope ps(p, PC_SOLVE, st);
   if (!forward_done)
     for (int k = 0; k < nt; k++)
-      hipLaunchKernelGGL(k_fwd_step, dim3(nt - k), dim3(256), 0, st, w->S, w->Linv, d_b, y, k);
+      hipLaunchKernelGGL(k_fwd_step<T>, dim3(nt - k), dim3(256), 0, st, w->S, w->Linv, d_b, y, k);
   for (int k = nt - 1; k >= 0; k--)
-    hipLaunchKernelGGL(k_bwd_step, dim3(k + 1), dim3(256), 0, st, w->S, w->Linv, w->D, y, d_b, k);
+    hipLaunchKernelGGL(k_bwd_step<T>, dim3(k + 1), dim3(256), 0, st, w->S, w->Linv, w->D, y, d_b, k);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
 
 // ---- C ABI: standalone dense solve (tests, roofline measurement) --------------------------------------------------------
-extern "C" int ba_dense_ldl_solve(int device, int64_t n, const double *a_lower_rowmajor, const double *b, double *x,
-                                  double *factor_ms) {
+template <typename T>
+static int dense_solve_host(int device, int64_t n, const double *a_lower_rowmajor, const double *b, double *x,
+                            double *factor_ms) {
   if (n <= 0 || !a_lower_rowmajor || !b || !x) {
     ba_set_error("ba_dense_ldl_solve: bad argument");
     return BA_ERR_ARG;
   }
   BA_HIP_CHECK(hipSetDevice(device));
   ba_problem tmp;  // only used for its (disabled) profiling slots
-  DenseLDL w;
-  int rc = dense_ldl_alloc(&w, n, nullptr);
+  DenseLDLT<T> w;
+  int rc = dense_ldl_alloc<T>(&w, n, nullptr);
   if (rc != BA_OK) return rc;
-  const int64_t nt = w.nt, npad = w.n;
-  std::vector<double> tiles((size_t)dense_ldl_tiles_doubles(n), 0.0);
+  const int64_t npad = w.n;
+  std::vector<T> tiles((size_t)dense_ldl_tiles_doubles(n), (T)0);
   for (int64_t i = 0; i < npad; i++) {
     int64_t ti = i / NB;
     for (int64_t j = 0; j <= i; j++) {
       int64_t tj = j / NB;
       double v = (i < n) ? a_lower_rowmajor[i * n + j] : (i == j ? 1.0 : 0.0);
-      tiles[(size_t)((tile_index(ti, tj) * NB + (i - ti * NB)) * NB + (j - tj * NB))] = v;
+      tiles[(size_t)((tile_index(ti, tj) * NB + (i - ti * NB)) * NB + (j - tj * NB))] = (T)v;
     }
   }
-  std::vector<double> bb((size_t)npad, 0.0);
-  for (int64_t i = 0; i < n; i++) bb[(size_t)i] = b[i];
-  double *d_b = nullptr;
+  std::vector<T> bb((size_t)npad, (T)0);
+  for (int64_t i = 0; i < n; i++) bb[(size_t)i] = (T)b[i];
+  T *d_b = nullptr;
   hipStream_t st = nullptr;
   hipEvent_t e0, e1;
-  BA_HIP_CHECK(hipMalloc((void **)&d_b, (size_t)npad * sizeof(double)));
-  BA_HIP_CHECK(hipMemcpy(w.S, tiles.data(), tiles.size() * sizeof(double), hipMemcpyHostToDevice));
-  BA_HIP_CHECK(hipMemcpy(d_b, bb.data(), (size_t)npad * sizeof(double), hipMemcpyHostToDevice));
+  BA_HIP_CHECK(hipMalloc((void **)&d_b, (size_t)npad * sizeof(T)));
+  BA_HIP_CHECK(hipMemcpy(w.S, tiles.data(), tiles.size() * sizeof(T), hipMemcpyHostToDevice));
+  BA_HIP_CHECK(hipMemcpy(d_b, bb.data(), (size_t)npad * sizeof(T), hipMemcpyHostToDevice));
   BA_HIP_CHECK(hipEventCreate(&e0));
   BA_HIP_CHECK(hipEventCreate(&e1));
   int zp = 0;
   BA_HIP_CHECK(hipEventRecord(e0, st));
   const bool fused = getenv("BA_LDL_SEPARATE_FORWARD") == nullptr;
-  rc = dense_ldl_factor(&tmp, &w, st, nullptr, fused ? d_b : nullptr);
+  rc = dense_ldl_factor<T>(&tmp, &w, st, nullptr, fused ? d_b : nullptr);
   BA_HIP_CHECK(hipEventRecord(e1, st));
-  if (rc == BA_OK) rc = dense_ldl_solve(&tmp, &w, d_b, st, fused);
+  if (rc == BA_OK) rc = dense_ldl_solve<T>(&tmp, &w, d_b, st, fused);
   BA_HIP_CHECK(hipMemcpy(&zp, w.flag, sizeof(int), hipMemcpyDeviceToHost));
   BA_HIP_CHECK(hipDeviceSynchronize());
   float ms = 0;
   BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   if (factor_ms) *factor_ms = ms;
-  BA_HIP_CHECK(hipMemcpy(bb.data(), d_b, (size_t)npad * sizeof(double), hipMemcpyDeviceToHost));
-  for (int64_t i = 0; i < n; i++) x[i] = bb[(size_t)i];
+  BA_HIP_CHECK(hipMemcpy(bb.data(), d_b, (size_t)npad * sizeof(T), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; i++) x[i] = (double)bb[(size_t)i];
   (void)hipFree(d_b);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  dense_ldl_free(&w);
-  (void)nt;
+  dense_ldl_free<T>(&w);
   if (rc == BA_OK && zp) {
     ba_set_error("dense LDL': exactly zero pivot");
     return BA_ERR_ZERO_PIVOT;
@@ -963,9 +1007,29 @@ extern "C" int ba_dense_ldl_solve(int device, int64_t n, const double *a_lower_r
   return rc;
 }
 
+extern "C" int ba_dense_ldl_solve(int device, int64_t n, const double *a_lower_rowmajor, const double *b, double *x,
+                                  double *factor_ms) {
+  return dense_solve_host<double>(device, n, a_lower_rowmajor, b, x, factor_ms);
+}
+
+// same with the matrix and right-hand side rounded to Float32 and factored / solved in Float32 (facto_type = Float32)
+extern "C" int ba_dense_ldl_solve_f32(int device, int64_t n, const double *a_lower_rowmajor, const double *b, double *x,
+                                      double *factor_ms) {
+  return dense_solve_host<float>(device, n, a_lower_rowmajor, b, x, factor_ms);
+}
+
+template int dense_ldl_alloc<double>(DenseLDLT<double> *, int64_t, double *);
+template int dense_ldl_alloc<float>(DenseLDLT<float> *, int64_t, float *);
+template void dense_ldl_free<double>(DenseLDLT<double> *);
+template void dense_ldl_free<float>(DenseLDLT<float> *);
+template int dense_ldl_factor<double>(ba_problem *, DenseLDLT<double> *, hipStream_t, int *, double *);
+template int dense_ldl_factor<float>(ba_problem *, DenseLDLT<float> *, hipStream_t, int *, float *);
+template int dense_ldl_solve<double>(ba_problem *, DenseLDLT<double> *, double *, hipStream_t, bool);
+template int dense_ldl_solve<float>(ba_problem *, DenseLDLT<float> *, float *, hipStream_t, bool);
+
 // micro-benchmark of the bulk trailing update (tools/bench_update.py): one pair update of an nt x nt tile matrix
 extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_out) {
-  BA_CHECK(set_kernel_attrs());
+  BA_CHECK(set_kernel_attrs<double>());
   const size_t tiles = (size_t)nt * (nt + 1) / 2 * NB * NB;
   double *S = nullptr, *V = nullptr;
   BA_HIP_CHECK(hipMalloc((void **)&S, tiles * sizeof(double)));
@@ -979,17 +1043,17 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   auto launch = [&]() {
     const double *V0 = V, *V1 = V + (size_t)nt * NB * NB;
     switch (variant) {
-      case 1: hipLaunchKernelGGL((k_ldl_update<1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
-      case 2: hipLaunchKernelGGL((k_ldl_update<1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
-      case 8: hipLaunchKernelGGL((k_ldl_update<1, 8>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
-      case 9: hipLaunchKernelGGL((k_ldl_update<1, 9>), dim3(grid), dim3(256), GEMM_LDS, 0, S, V0, V1, 0, 2, nt, nblk); break;
-      default: hipLaunchKernelGGL((k_ldl_update<1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS, 0, S, V0, V1, 0, 2, nt, nblk);
+      case 1: hipLaunchKernelGGL((k_ldl_update<double, 1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk); break;
+      case 2: hipLaunchKernelGGL((k_ldl_update<double, 1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk); break;
+      case 8: hipLaunchKernelGGL((k_ldl_update<double, 1, 8>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk); break;
+      case 9: hipLaunchKernelGGL((k_ldl_update<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk); break;
+      default: hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk);
     }
   };
   {
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_ldl_update<1, 0>), 256, GEMM_LDS);
-    if (variant == 0) fprintf(stderr, "[debug] update<1>: occupancy API says %d workgroups/CU at %zu B LDS\n", nb, GEMM_LDS);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_ldl_update<double, 1, 0>), 256, GEMM_LDS_ELEMS * sizeof(double));
+    if (variant == 0) fprintf(stderr, "[debug] update<1>: occupancy API says %d workgroups/CU at %zu B LDS\n", nb, GEMM_PRIV_LDS_ELEMS * sizeof(double));
   }
   launch();
   BA_HIP_CHECK(hipDeviceSynchronize());
@@ -1007,7 +1071,7 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
 
 // diagnostic: phase cycle counts of the diagonal-tile kernel (load, pivots, inverse16, trsm16+syrk16, full inverse, store)
 extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
-  BA_CHECK(set_kernel_attrs());
+  BA_CHECK(set_kernel_attrs<double>());
   double *S = nullptr, *Li = nullptr, *D = nullptr;
   int *flag = nullptr;
   unsigned long long *st = nullptr;
@@ -1026,7 +1090,7 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
   for (int rep = 0; rep < 3; rep++) {
     BA_HIP_CHECK(hipMemcpy(S, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
     BA_HIP_CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), DIAG_LDS, 0, S, Li, D, flag, rep == 2 ? st : nullptr);
+    hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(double), 0, S, Li, D, flag, rep == 2 ? st : nullptr);
     BA_HIP_CHECK(hipEventRecord(e1, 0));
     BA_HIP_CHECK(hipEventSynchronize(e1));
     if (rep == 1) BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));

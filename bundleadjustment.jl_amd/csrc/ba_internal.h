@@ -57,18 +57,20 @@ struct ProfSlot {
   int64_t calls = 0;
 };
 
-struct DenseLDL {  // workspace of the blocked LDL^T, n = 9*ncams padded to nt*NB
+template <typename T>
+struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*ncams padded to nt*NB
   int64_t n = 0, nt = 0;
-  double *S = nullptr;     // packed lower tiles (may alias the caller's reduce buffer)
-  double *V = nullptr;     // 4 x nt tiles: V_i = L_ik * D_k of two panel pairs (double-buffered for the look-ahead)
-  double *Linv = nullptr;  // nt tiles: inverse of each unit-lower diagonal tile
-  double *D = nullptr;     // nt*NB pivots
+  T *S = nullptr;          // packed lower tiles (may alias the caller's reduce buffer)
+  T *V = nullptr;          // 4 x nt tiles: V_i = L_ik * D_k of two panel pairs (double-buffered for the look-ahead)
+  T *Linv = nullptr;       // nt tiles: inverse of each unit-lower diagonal tile
+  T *D = nullptr;          // nt*NB pivots (+ nt*NB scratch)
   int *flag = nullptr;     // device int: set to 1 on an exactly zero pivot
   bool own_S = true;
   hipStream_t side = nullptr, bulk = nullptr;      // look-ahead: panel chain / bulk update streams (disjoint CU masks)
   int side_cus = 0;                                 // 0: no CU-masked streams, factorisation runs on one stream
   hipEvent_t ev_chain = nullptr, ev_bulk = nullptr;
 };
+typedef DenseLDLT<double> DenseLDL;
 
 struct ba_problem {
   int device = 0;
@@ -138,15 +140,19 @@ int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, doubl
                       hipStream_t st);
 
 // ---- dense LDL^T (ba_dense_ldl.hip) ---------------------------------------------------------------
-int dense_ldl_alloc(DenseLDL *w, int64_t n_unpadded, double *external_S);
-void dense_ldl_free(DenseLDL *w);
-int64_t dense_ldl_tiles_doubles(int64_t n_unpadded);
+template <typename T>
+int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S);
+template <typename T>
+void dense_ldl_free(DenseLDLT<T> *w);
+int64_t dense_ldl_tiles_doubles(int64_t n_unpadded);  // number of ELEMENTS of the packed lower tiles
 // factor S in place (L below the diagonal tiles' diagonal, D separately); *zero_pivot set on exact zero pivot.
 // d_b != null: the forward substitution L y = b of that right-hand side (length nt*NB, clobbered) is fused into the
 // panel solves; pass forward_done = true to dense_ldl_solve afterwards.
-int dense_ldl_factor(ba_problem *p, DenseLDL *w, hipStream_t st, int *zero_pivot, double *d_b);
+template <typename T>
+int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b);
 // solve S x = b for one right-hand side held in d_b (length nt*NB, overwritten by x)
-int dense_ldl_solve(ba_problem *p, DenseLDL *w, double *d_b, hipStream_t st, bool forward_done);
+template <typename T>
+int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool forward_done);
 
 // ---- LM (ba_lm.hip) ---------------------------------------------------------------------------------
 void lm_free(ba_problem *p);

@@ -140,7 +140,35 @@ struct LMState {
 
 struct LMWorkFull : LMWork {
   LMState s;
+  // facto_type = Float32 (src/lm.jl:170-173): Float32 copy of the reduced camera system, allocated on first use
+  DenseLDLT<float> ldl32;
+  float *rhs32 = nullptr;
+  bool have32 = false, last_f32 = false;
 };
+
+namespace {
+template <typename A, typename B>
+__global__ void k_convert(const A *__restrict__ in, B *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (B)in[i];
+}
+template <typename A, typename B>
+int launch_convert(const A *in, B *out, int64_t n, hipStream_t st) {
+  if (n <= 0) return BA_OK;
+  const int64_t blocks = std::min<int64_t>((n + 255) / 256, 1 << 16);
+  hipLaunchKernelGGL((k_convert<A, B>), dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+}  // namespace
+
+static int ensure_f32(LMWorkFull *w) {
+  if (w->have32) return BA_OK;
+  BA_CHECK(dense_ldl_alloc<float>(&w->ldl32, w->n, nullptr));
+  BA_HIP_CHECK(hipMalloc((void **)&w->rhs32, (size_t)w->npad * sizeof(float)));
+  w->have32 = true;
+  return BA_OK;
+}
 
 static int lm_ensure(ba_problem *p) {
   if (p->lm) return BA_OK;
@@ -194,6 +222,10 @@ void lm_free(ba_problem *p) {
   if (!p->lm) return;
   LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
   dense_ldl_free(&w->ldl);
+  if (w->have32) {
+    dense_ldl_free(&w->ldl32);
+    (void)hipFree(w->rhs32);
+  }
   void *ptrs[] = {w->x, w->x_trial, w->delta, w->r, w->r_trial, w->J, w->Hpp, w->gp, w->Uinv, w->u, w->Hcc,
                   w->partial, w->colscale, w->Yobs, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
                   w->tasks.task_a, w->tasks.task_b, w->s.own_red ? w->s.red : nullptr};
@@ -241,7 +273,8 @@ static int fetch_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 }
 
 // delta = -(J'J + lambda I)^-1 J'r at the current linearisation; also |J delta + r|^2 -> SH_MODEL, |delta|^2
-static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, hipStream_t st) {
+static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, hipStream_t st,
+                       bool facto_f32 = false) {
   // every rank holds partial Hcc / Schur sums; the lambda I of the camera block is added by rank 0 only
   const double lam_diag = (p->rank == 0) ? lambda : 0.0;
   BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st));
@@ -256,14 +289,22 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
     BA_CHECK(launch_scale_S(p, w->n, w->ldl.nt, w->colscale, w->ldl.S, st));
     BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));
   }
-  int zp = 0;
-  BA_CHECK(dense_ldl_factor(p, &w->ldl, st, nullptr, w->rhs));  // forward substitution of rhs rides along
-  BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st, true));
+  w->last_f32 = facto_f32;
+  if (facto_f32) {  // round the assembled system to Float32, factor and solve there, widen the solution
+    BA_CHECK(ensure_f32(w));
+    BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, dense_ldl_tiles_doubles(w->n), st));
+    BA_CHECK(launch_convert(w->rhs, w->rhs32, w->npad, st));
+    BA_CHECK(dense_ldl_factor<float>(p, &w->ldl32, st, nullptr, w->rhs32));
+    BA_CHECK(dense_ldl_solve<float>(p, &w->ldl32, w->rhs32, st, true));
+    BA_CHECK(launch_convert(w->rhs32, w->rhs, w->npad, st));
+  } else {
+    BA_CHECK(dense_ldl_factor(p, &w->ldl, st, nullptr, w->rhs));  // forward substitution of rhs rides along
+    BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st, true));
+  }
   double *dc = w->delta + 3 * p->npnts;
   if (normalize != 0) BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));  // dc = D^-1 dc'
   BA_HIP_CHECK(hipMemcpyAsync(dc, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
   BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->u, dc, w->delta, st));
-  (void)zp;
   return BA_OK;
 }
 
@@ -283,7 +324,7 @@ static int trial_point(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 
 static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
   int h = 0;
-  BA_HIP_CHECK(hipMemcpyAsync(&h, w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  BA_HIP_CHECK(hipMemcpyAsync(&h, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
   BA_HIP_CHECK(hipStreamSynchronize(st));
   if (h) {
     ba_set_error("reduced camera system: exactly zero pivot (SQDException in the reference)");
@@ -363,10 +404,6 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     ba_set_error("ba_lm_solve: normalize != :None is single-GPU only for now (Hcc is not all-reduced)");
     return BA_ERR_ARG;
   }
-  if (o->facto_f32) {
-    ba_set_error("ba_lm_solve: facto_type = Float32 is not implemented yet");
-    return BA_ERR_ARG;
-  }
   BA_HIP_CHECK(hipSetDevice(p->device));
   const double t_start = wall();
   BA_CHECK(lm_ensure(p));
@@ -414,7 +451,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   while (!(small_step || first_order || small_residual || small_obj_change || tired || fail2)) {
     if (V) iter++;                                                                           // lm.jl:127
     if (!V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);  // LevenbergMarquardt.jl:143-147
-    if ((rc = linear_step(p, w, lambda, o->normalize, st)) != BA_OK) break;
+    if ((rc = linear_step(p, w, lambda, o->normalize, st, V && o->facto_f32)) != BA_OK) break;
     stats->n_factor++;
     if ((rc = step_scalars(p, w, st)) != BA_OK) break;
     if ((rc = trial_point(p, w, st)) != BA_OK) break;  // lm.jl:251-254
@@ -423,7 +460,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     if ((rc = fetch_scalars(p, w, st)) != BA_OK) break;
     {
       int h = 0;
-      hipError_t e = hipMemcpy(&h, w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost);
+      hipError_t e = hipMemcpy(&h, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost);
       if (e != hipSuccess) {
         ba_set_error("pivot flag copy: %s", hipGetErrorString(e));
         rc = BA_ERR_HIP;

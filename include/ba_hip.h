@@ -177,6 +177,10 @@ int ba_profile_get(ba_problem *p, int cap, const char **names, double *total_ms,
  * solve A x = b.  status BA_ERR_ZERO_PIVOT on an exactly zero pivot. */
 int ba_dense_ldl_solve(int device, int64_t n, const double *a_lower_rowmajor, const double *b, double *x,
                        double *factor_ms);
+/* the same with matrix and right-hand side rounded to Float32, factored and solved in Float32 (what
+ * facto_type = Float32 does to the reduced camera system; src/lm.jl:170-173 does it to the augmented matrix) */
+int ba_dense_ldl_solve_f32(int device, int64_t n, const double *a_lower_rowmajor, const double *b, double *x,
+                           double *factor_ms);
 
 #ifdef __cplusplus
 }

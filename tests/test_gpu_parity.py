@@ -167,6 +167,18 @@ def test_dense_ldl_vs_numpy(ba, n, gpu_ok):
     assert np.linalg.norm(x - x_ref) <= 1e-10 * np.linalg.norm(x_ref) * np.linalg.cond(A) ** 0.5
 
 
+@pytest.mark.parametrize("n", [64, 300, 1000])
+def test_dense_ldl_f32(ba, n, gpu_ok):
+    """Float32 factor/solve (facto_type = Float32): Float32-level accuracy against the Float64 solution."""
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n + 8))
+    A = G @ G.T / n + np.eye(n)  # well conditioned
+    b = rng.standard_normal(n)
+    x, ms = ba._lib.dense_ldl_solve(A, b, f32=True)
+    x_ref = np.linalg.solve(A, b)
+    assert np.linalg.norm(x - x_ref) <= 1e-4 * np.linalg.norm(x_ref)
+
+
 def test_dense_ldl_indefinite_and_zero_pivot(ba, gpu_ok):
     # LDL' without pivoting accepts negative pivots (quasi-definite input), like src/ldl_aux.jl
     rng = np.random.default_rng(5)
@@ -232,6 +244,26 @@ def test_lm_normalize_vs_oracle(ba, orc, small_prob, gpu_ok, norm, code):
                                               variant=1, normalize=code)
     assert rc == 0 and st.iter == st_ref.iter and st.status == orc.STATUS[st_ref.status]
     assert abs(st.objective - st_ref.objective) <= 1e-8 * st_ref.objective
+    m.close()
+
+
+def test_lm_facto_f32(ba, orc, small_prob, gpu_ok):
+    """facto_type = Float32 (src/lm.jl:170-173, src/diffprecsions.jl:39-41): the factorisation runs in Float32, the
+    rest in Float64.  Float32 rounding of the step moves the iterates, so the oracle's Float32 run and the Float64 run
+    are compared on what both must reach: the same final objective to Float32-level accuracy."""
+    p = small_prob
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    st32 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "LDL", "AMD", "None", False, facto_type=np.float32)
+    st64 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "LDL", "AMD", "None", False, facto_type=np.float64)
+    rc, x_ref, st_ref, log_ref = orc.lm_solve(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"],
+                                              variant=1, facto_f32=True)
+    print("f32:", st32.status, st32.iter, st32.objective, "f64:", st64.iter, st64.objective, "oracle f32:", st_ref.iter,
+          st_ref.objective)
+    assert rc == 0
+    assert st32.status in ("first_order", "small_residual", "acceptable", "small_step")
+    assert abs(st32.objective - st_ref.objective) <= 1e-3 * st_ref.objective
+    assert abs(st32.objective - st64.objective) <= 1e-3 * st64.objective
+    assert st32.objective != st64.objective or st32.iter != st64.iter or not np.array_equal(st32.solution, st64.solution)
     m.close()
 
 
