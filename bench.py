@@ -28,6 +28,22 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_F64_PEAK_TF = 78.6    # MI355X FP64 matrix peak (vendor sheet; v_mfma_f64_16x16x4_f64, 2048 flop / 64 clk / SIMD)
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this workload (profiles/pmc_traffic_<workload>.json,
+    written by tools/collect_pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this very command; the
+    counters cannot be read from inside the timed process).  None when no such measurement is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, v in k.items():
+        if name.startswith(kernel):
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,18 +163,22 @@ def main():
     if prof:
         name, (ms, calls) = max(prof.items(), key=lambda kv: kv[1][0])
         n_fact = max(1, prof["k_ldl_diag"][1] // max(1, (9 * ncams + 127) // 128))
-        if name == "k_ldl_syrk":
+        if name == "k_ldl_update":
+            # one launch per panel pair (k, k+1), k even: S_ij -= V0_i L_jk' + V1_i L_j,k+1' for the m(m+1)/2 lower tiles
+            # right of tile column k+3, m = nt-k-4: 2 tile products of 2*128^3 flop each (kernel table)
             nt = (9 * ncams + 127) // 128
-            tiles = sum((nt - k - 1) * (nt - k) // 2 for k in range(nt))
-            flops = n_fact * tiles * 2.0 * 128 ** 3
+            tiles = sum((nt - k - 4) * (nt - k - 3) // 2 for k in range(0, nt - 2, 2) if nt - k - 4 > 0)
+            flops = n_fact * tiles * 2 * 2.0 * 128 ** 3
             ach = flops / (ms * 1e-3) / 1e12
             roof = dict(kernel=name, bound="mfma", achieved=ach, peak=MFMA_F64_PEAK_TF, unit="TFLOP/s",
-                        frac=ach / MFMA_F64_PEAK_TF, traffic=None, avg_launch_ms=ms / calls, launches=calls)
+                        frac=ach / MFMA_F64_PEAK_TF, traffic=pmc_traffic(args.workload, name),
+                        avg_launch_ms=ms / calls, launches=calls, flops_per_launch=flops / calls)
         else:
-            roof = dict(kernel=name, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
+            roof = dict(kernel=name, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None,
+                        traffic=pmc_traffic(args.workload, name),
                         avg_launch_ms=ms / calls, launches=calls)
     roof_jac = dict(kernel="k_jac_coord", bound="hbm", achieved=jac_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=jac_gbs / HBM_PEAK_GBS, traffic=None, avg_launch_ms=jac_ms,
+                    frac=jac_gbs / HBM_PEAK_GBS, traffic=pmc_traffic(args.workload, "k_jac_coord"), avg_launch_ms=jac_ms,
                     bytes_per_obs=208.0 + 8.0 * nvar_g / nobs_g)
     if roof is None:
         roof = roof_jac

@@ -851,7 +851,7 @@ static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, bool fir
                        hipStream_t st) {
   const int nt = (int)w->nt, m = nt - base;
   if (m <= 0) return BA_OK;
-  ProfScope ps(p, PC_LDL_SYRK, st);
+  ProfScope ps(p, first2 ? PC_LDL_SYRK : PC_LDL_UPDATE, st);
   if (first2) {
     const int nblk = m + (m > 1 ? m - 1 : 0);
     hipLaunchKernelGGL(k_ldl_pair2_rs<T>, dim3(4 * nblk), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, V0, V1, k, base, nt);

@@ -42,7 +42,8 @@ enum ProfClass {
   PC_SCHUR_RHS,
   PC_LDL_DIAG,
   PC_LDL_TRSM,
-  PC_LDL_SYRK,
+  PC_LDL_SYRK,    // column / two-column updates feeding the next panels (k_ldl_col_rs, k_ldl_pair2_rs)
+  PC_LDL_UPDATE,  // bulk pair update of the trailing matrix (k_ldl_update)
   PC_SOLVE,
   PC_BACKSUB,
   PC_TRIAL,

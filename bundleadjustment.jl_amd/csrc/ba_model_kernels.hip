@@ -109,15 +109,33 @@ __global__ __launch_bounds__(BLK) void k_jac_structure(int64_t nobs, int64_t npn
 // Unlike the residual (which keeps the reference's operation order), this block is tolerance-matched by
 // contract (the reference's own values depend on OpenBLAS' summation order, SURVEY.md 8c: <= 1e-12 of the
 // block inf-norm), so the ten divisions by theta and z are two reciprocals and a*b+c contracts to FMA.
+// The part of the block that depends on the camera only (theta, the unit axis, sin and cos): evaluated once per camera
+// by k_cam_pre instead of once per observation.  Row layout (CPAD = 16 elements, one 128-byte line for double):
+//   [kx ky kz | t(3) | k1 k2 f | sin cos 1/theta | 0 0 0 0]
 template <typename T>
-__device__ inline void jac_block(const T X[3], const T C[9], T J[24]) {
+__device__ inline void cam_pre(const T C[9], T P[12]) {
 #pragma clang fp contract(fast)
-  const T x = X[0], y = X[1], z = X[2];
   const T th = Trig<T>::sq(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
   const T ith = (T)1 / th;
-  const T kx = C[0] * ith, ky = C[1] * ith, kz = C[2] * ith;
   T s, c;
   Trig<T>::sc(th, s, c);
+  P[0] = C[0] * ith;
+  P[1] = C[1] * ith;
+  P[2] = C[2] * ith;
+#pragma unroll
+  for (int i = 3; i < 9; i++) P[i] = C[i];
+  P[9] = s;
+  P[10] = c;
+  P[11] = ith;
+}
+
+template <typename T>
+__device__ inline void jac_block(const T X[3], const T P[12], T J[24]) {
+#pragma clang fp contract(fast)
+  const T x = X[0], y = X[1], z = X[2];
+  const T kx = P[0], ky = P[1], kz = P[2];
+  const T s = P[9], c = P[10], ith = P[11];
+  const T *C = P;  // C[3..8] = t, k1, k2, f as in the camera block
   const T d = kx * x + ky * y + kz * z;
   const T omc = 1 - c;
   const T omc_d = omc * d;
@@ -211,119 +229,254 @@ __device__ inline void jac_block(const T X[3], const T C[9], T J[24]) {
 // jac_coord!: one lane per observation computes its 24 values in registers; each wave transposes its 64 x 24 values
 // through its own LDS slot (row stride 25 elements: conflict-free ds_write_b64 / ds_read_b64) so that every wave store
 // instruction writes 1 KiB of consecutive addresses.
-// Each wave handles NBW = 4 consecutive batches of 64 observations, straight-line (no loop: inside a loop the compiler
-// hoists the ~100 fp64 constants of sincos into registers, 240 VGPRs): the index pairs and the point/camera blocks of
-// ALL its batches are requested up front, so the index -> gather latency is paid once per 256 observations and the
-// stores of one batch drain while the next is computed.  Measured on Venice (5.0 M observations, 1.03 GB of HBM traffic
-// by the TCC counters = the algorithmic bytes): NBW 1 / 2 / 4 -> 0.295 / 0.285 / 0.260 ms; the arithmetic is free
-// (0.26 ms with it removed), the stores alone take 0.18 ms, the loads alone 0.07 ms.
-// DBG (tools/bench_jac.py only): 1 = skip the arithmetic, 2 = skip the stores.
-#ifndef BA_NBW
-#define BA_NBW 4
-#endif
-constexpr int NBW = BA_NBW;
+//
+// Software-pipelined persistent waves.  The kernel is 93 % stores (192 of 205 bytes per observation) and a CU's vector
+// memory instructions are served in order: a load issued behind the 12 KB-per-batch stores of the CU's other waves
+// waits for them to drain, and the index -> gather dependency pays that wait twice.  With one batch per wave (or
+// NBW = 4 straight-line batches, all loads up front) the two phases simply add up -- measured on Venice
+// (5.0 M observations): stores alone 0.18 ms, + loads 0.26 ms, the arithmetic being free either way.  So every wave
+// loops over batches b, b + W, b + 2W, ... and at the top of iteration i requests the index pairs of batch i + 2 and
+// the point / camera rows of batch i + 1 (whose indices arrived an iteration ago) before it computes and stores batch
+// i: no load is waited for in the iteration that issued it.  The trigonometric part of the block is per camera
+// (cam_pre, k_cam_pre) -- which also keeps the loop body free of the ~100 fp64 sincos constants the compiler would
+// hoist into registers.
+// DBG (tools/bench_jac.py only): 1 = skip the arithmetic, 2 = skip the stores, 4 = no loads, 8 = no LDS transpose.
+constexpr int CPAD = 16;  // precomputed camera rows: 16 elements (one 128-byte line for double), 16-byte aligned
 
-constexpr int CPAD = 16;  // camera rows are re-laid out to 16 elements (one 128-byte line for double) before the launch
-
-// x's camera block (9 per camera, 8-byte aligned rows) -> padded, 16-byte aligned rows.  Why: a lane fetching its camera
-// with nine 8-byte loads makes every one of the nine wave instructions pull 64 different cache lines through the CU's
-// 64 B/clk L1 fill path, which the 12 KB of stores per batch need as well (measured: gathers and stores add up, 0.29 ms);
-// five 16-byte loads of one aligned line fetch each line once.
+// x's camera block (9 per camera) -> cam_pre rows.  Besides hoisting the per-camera arithmetic, the padded rows make
+// the gather five or six aligned 16-byte loads of ONE cache line per lane instead of nine 8-byte loads straddling two.
 template <typename T>
-__global__ __launch_bounds__(BLK) void k_pad_cams(int64_t ncams, const T *__restrict__ cams, T *__restrict__ padded) {
-  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  if (i >= ncams * CPAD) return;
-  int64_t c = i / CPAD;
-  int j = (int)(i - c * CPAD);
-  padded[i] = j < 9 ? cams[9 * c + j] : (T)0;
+__global__ __launch_bounds__(BLK) void k_cam_pre(int64_t ncams, const T *__restrict__ cams, T *__restrict__ pre) {
+  int64_t c = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (c >= ncams) return;
+  T C[9], P[12];
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = cams[9 * c + i];
+  cam_pre<T>(C, P);
+#pragma unroll
+  for (int i = 0; i < CPAD; i++) pre[CPAD * c + i] = i < 12 ? P[i] : (T)0;
 }
+
+template <typename T, int DBG>
+__device__ inline void jac_load_idx(int64_t b, int lane, int64_t nobs, const int *__restrict__ cam0,
+                                    const int *__restrict__ pnt0, int &pi, int &ci) {
+  int64_t o = b * 64 + lane;
+  o = o < nobs ? o : nobs - 1;  // batches past the end re-read the last observation: always a valid address
+  pi = (DBG & 4) ? (int)(o & 1023) : pnt0[o];
+  ci = (DBG & 4) ? (int)(o & 511) : cam0[o];
+}
+
+// Camera rows of one batch, requested line by line: CPAD / VL lanes share one observation and fetch the 16-byte pieces of
+// ITS row (a full, aligned cache line per observation and instruction quad), instead of every lane walking its own
+// row with six loads that each touch 64 different lines.  Measured on top of the 0.18 ms store stream of Venice: the
+// lane-per-row gather costs +0.08 ms, index and point loads together +0.02 ms -- the L1's line-at-a-time tag path, which
+// the stores need too, is what the divergent gather occupies.  The pieces land in registers (stg), cross to the lane
+// that owns the observation through the wave's LDS slot (row stride CSTR dwords: conflict-free ds_read_b128).
+template <typename T>
+struct CamStage {
+  static constexpr int VL = 16 / sizeof(T);       // elements per 16-byte piece
+  static constexpr int PIECES = 12 / VL;           // pieces that carry data (6 double / 3 float)
+  static constexpr int LPO = CPAD / VL;            // lanes per observation = pieces per row (8 / 4)
+  static constexpr int OPI = 64 / LPO;             // observations per load instruction (8 / 16)
+  static constexpr int NI = LPO;                   // load instructions per batch
+  static constexpr int CSTR = sizeof(T) == 8 ? 28 : 20;  // LDS row stride in dwords
+  typedef T vt __attribute__((ext_vector_type(VL)));
+};
+
+// The row requests are inline assembly on purpose.  Written as ordinary loads they are sunk by instruction selection to
+// their first use -- behind the batch's stores -- and vmcnt retires in issue order, so the wave would wait for its own
+// 12 KB of stores before it may touch the rows (measured: no gain over the unpipelined kernel).  As opaque asm the
+// requests stay where they are written, ahead of the stores; jac_wait_cam<N> is their s_waitcnt, N = the VMEM
+// instructions issued after them that may stay in flight.  Between the two the destination registers hold nothing:
+// the asm operands tie them to the wait, so no compiler-generated use can precede it (tools/check_jac_isa.py checks the
+// generated code for a stray read).  Compiler-counted waits elsewhere stay safe: an untracked older request only makes
+// a counted wait stricter.
+template <typename T, int DBG>
+__device__ inline void jac_issue_cam(int ci, int lane, const T *__restrict__ cpre, typename CamStage<T>::vt stg[CamStage<T>::NI]) {
+  typedef CamStage<T> S;
+  const int piece = lane % S::LPO, sub = lane / S::LPO;
+#pragma unroll
+  for (int j = 0; j < S::NI; j++) {
+    const int c = __shfl(ci, j * S::OPI + sub, 64);
+    if (DBG & 16) {
+#pragma unroll
+      for (int e = 0; e < S::VL; e++) stg[j][e] = (T)(c + e);
+    } else {  // every lane loads: the pieces past the data are the row's zero padding
+      const typename S::vt *src = reinterpret_cast<const typename S::vt *>(cpre + CPAD * (int64_t)c) + piece;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(stg[j]) : "v"(src) : "memory");
+    }
+  }
+}
+
+template <typename T, int NAFTER>
+__device__ inline void jac_wait_cam(typename CamStage<T>::vt stg[CamStage<T>::NI]) {
+  if constexpr (CamStage<T>::NI == 8)
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7])
+                 : "n"(NAFTER)
+                 : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]) : "n"(NAFTER) : "memory");
+}
+
+template <typename T>
+__device__ inline void jac_land_cam(const typename CamStage<T>::vt stg[CamStage<T>::NI], int lane, T *ws, T P[12]) {
+  typedef CamStage<T> S;
+  const int piece = lane % S::LPO, sub = lane / S::LPO;
+  unsigned *w32 = reinterpret_cast<unsigned *>(ws);
+  if (piece < S::PIECES) {
+#pragma unroll
+    for (int j = 0; j < S::NI; j++)
+      *reinterpret_cast<typename S::vt *>(w32 + (j * S::OPI + sub) * S::CSTR + 4 * piece) = stg[j];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int u = 0; u < S::PIECES; u++) {
+    const typename S::vt v = *reinterpret_cast<const typename S::vt *>(w32 + lane * S::CSTR + 4 * u);
+#pragma unroll
+    for (int e = 0; e < S::VL; e++) P[u * S::VL + e] = v[e];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // the slot is rewritten by the block transpose
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T, int DBG>
+__device__ inline void jac_gather_point(int pi, const T *__restrict__ x, T X[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) X[i] = (DBG & (4 | 32)) ? (T)(pi + i) : x[3 * (int64_t)pi + i];
+}
+
+// Block of one batch: 24 values per lane -> LDS transpose -> 16-byte stores of consecutive addresses.  FULL: all 64
+// observations exist, nothing is predicated -- the pipelined loop needs that: with stores inside branches the compiler
+// cannot count them and falls back to s_waitcnt vmcnt(0) before the next use of a prefetched register, which makes every
+// wave wait for its own stores and serialises the load and store phases again.
+template <typename T, int DBG, bool FULL>
+__device__ inline void jac_emit(const T X0[3], const T P0[12], T *ws, int lane, int64_t b0, int64_t nobs,
+                                T *__restrict__ vals) {
+  constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte store
+  T J[24];
+  if (DBG & 1) {
+#pragma unroll
+    for (int j = 0; j < 24; j++) J[j] = X0[j % 3] + P0[j % 12];
+  } else {
+    jac_block<T>(X0, P0, J);
+  }
+  if ((FULL || b0 + lane < nobs) && !(DBG & 8)) {
+#pragma unroll
+    for (int j = 0; j < 24; j++) ws[lane * 25 + j] = J[j];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int64_t nvalid = FULL ? 64 * 24 : (nobs - b0) * 24;
+  T *out = vals + b0 * 24;
+#pragma unroll
+  for (int it = 0; it < 24 / VEC; it++) {
+    const int e = (it * 64 + lane) * VEC;
+    if ((FULL || e < nvalid) && !(DBG & 2)) {
+      typedef T vst __attribute__((ext_vector_type(VEC)));
+      vst w;
+#pragma unroll
+      for (int r = 0; r < VEC; r++) {
+        const int ee = e + r, oo = ee / 24;
+        w[r] = (DBG & 8) ? J[(it * VEC + r) % 24] : ws[oo * 25 + (ee - oo * 24)];
+      }
+      // Non-temporal 16-byte store: the 0.96 GB stream is not kept in L2, where it would evict the camera rows and the
+      // index / point lines every batch re-reads.  Measured on Venice, same box: plain stores 0.255-0.261 ms, nt stores
+      // 0.192-0.196 ms.  DBG & 64 (bench only): plain stores.  (Use the builtin, not hand-written asm stores: an
+      // inline-asm `global_store_dwordx4 ... sc1` without the wait state hipcc inserts after a >64-bit store whose
+      // data registers are rewritten corrupted 0.5 % of the blocks at 12 M observations -- tools/dbg_big.py.)
+      if (DBG & 64) *reinterpret_cast<vst *>(out + e) = w;
+      else __builtin_nontemporal_store(w, reinterpret_cast<vst *>(out + e));
+    }
+  }
+  if (DBG & 2) {  // keep the values alive without storing them
+    T acc = 0;
+#pragma unroll
+    for (int j = 0; j < 24; j++) acc += J[j];
+    if (acc == (T)12345.678) vals[0] = acc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // the slot is rewritten by the next batch's camera rows
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename T, int DBG = 0>
 __global__ __launch_bounds__(BLK) void k_jac_coord(int64_t nobs, int64_t npnts, const int *__restrict__ cam0,
                                                     const int *__restrict__ pnt0, const T *__restrict__ x,
-                                                    const T *__restrict__ cpad, T *__restrict__ vals) {
-  __shared__ T tile[BLK / 64][64 * 25];
+                                                    const T *__restrict__ cpre, T *__restrict__ vals) {
+  typedef CamStage<T> S;
+  constexpr int CDBG = (DBG & 4) ? (DBG | 16) : DBG;
+  constexpr int NST = (DBG & 2) ? 0 : (int)(24 * sizeof(T) / 16);  // store instructions of a full batch (12 / 6)
+  __shared__ __attribute__((aligned(16))) T tile[BLK / 64][64 * 25];
+  static_assert(64 * S::CSTR * 4 <= 64 * 25 * sizeof(T), "camera staging must fit the wave's transpose slot");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t w0 = ((int64_t)blockIdx.x * (BLK / 64) + wv) * (64 * NBW);  // first observation of this wave
-  if (w0 >= nobs) return;
-  constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte store
+  const int64_t nfull = nobs / 64;                      // batches with all 64 observations
+  const int64_t nw = (int64_t)gridDim.x * (BLK / 64);  // waves in the grid = batch stride of one wave
+  const int64_t wid = (int64_t)blockIdx.x * (BLK / 64) + wv;
   T *ws = tile[wv];
-  T X[NBW][3], C[NBW][9];
-  int pi[NBW], ci[NBW];
+  typename S::vt stg[S::NI];
+  T X0[3], P0[12];
+  if (wid < nfull) {
+    int64_t b = wid;
+    int pi1, ci1;
+    {  // first batch: loaded and landed before the loop, so that nothing is pending where the loop is entered (a load
+       // still in flight there would make the compiler wait for the loop's own stores at the same program point)
+      int pi0, ci0;
+      jac_load_idx<T, DBG>(b, lane, nobs, cam0, pnt0, pi0, ci0);
+      jac_load_idx<T, DBG>(b + nw, lane, nobs, cam0, pnt0, pi1, ci1);
+      jac_gather_point<T, DBG>(pi0, x, X0);
+      jac_issue_cam<T, CDBG>(ci0, lane, cpre, stg);
+      jac_wait_cam<T, 0>(stg);
+      jac_land_cam<T>(stg, lane, ws, P0);
+      // make the compiler's own wait for these loads happen here: pending at the loop header they would be merged with
+      // the back edge's state into an s_waitcnt vmcnt(0) that also waits for the loop's stores
+      asm volatile("" ::"v"(pi1), "v"(ci1), "v"(X0[0]), "v"(X0[1]), "v"(X0[2]));
+    }
+    for (; b < nfull; b += nw) {  // every wave's trip count is bounded by nfull: no wave waits on another
+      int pi2, ci2;
+      T X1[3];
+      jac_load_idx<T, DBG>(b + 2 * nw, lane, nobs, cam0, pnt0, pi2, ci2);  // indices two batches ahead
+      jac_gather_point<T, DBG>(pi1, x, X1);                                // point and camera rows one batch ahead,
+      jac_issue_cam<T, CDBG>(ci1, lane, cpre, stg);                        // requested BEFORE this batch's stores
+      jac_emit<T, DBG, true>(X0, P0, ws, lane, b * 64, nobs, vals);
+      jac_wait_cam<T, NST>(stg);  // the stores just issued stay in flight
+      jac_land_cam<T>(stg, lane, ws, P0);
 #pragma unroll
-  for (int q = 0; q < NBW; q++) {  // all index pairs first (one latency), then all gathers (one more)
-    int64_t o = w0 + 64 * q + lane;
-    o = o < nobs ? o : nobs - 1;
-    pi[q] = pnt0[o];
-    ci[q] = cam0[o];
-  }
-#pragma unroll
-  for (int q = 0; q < NBW; q++) {
-    const int p0 = pi[q], c0 = ci[q];
-#pragma unroll
-    for (int i = 0; i < 3; i++) X[q][i] = x[3 * (int64_t)p0 + i];
-    {
-      constexpr int VL = 16 / sizeof(T);  // elements per 16-byte load
-      typedef T vt __attribute__((ext_vector_type(VL)));
-      const vt *row = reinterpret_cast<const vt *>(cpad + CPAD * (int64_t)c0);
-      T tmp[((9 + VL - 1) / VL) * VL];
-#pragma unroll
-      for (int u = 0; u < (9 + VL - 1) / VL; u++) {
-        vt v = row[u];
-#pragma unroll
-        for (int e2 = 0; e2 < VL; e2++) tmp[u * VL + e2] = v[e2];
-      }
-#pragma unroll
-      for (int i = 0; i < 9; i++) C[q][i] = tmp[i];
+      for (int i = 0; i < 3; i++) X0[i] = X1[i];
+      pi1 = pi2;
+      ci1 = ci2;
     }
   }
-#pragma unroll
-  for (int q = 0; q < NBW; q++) {
-    const int64_t b0 = w0 + 64 * q;
-    if (b0 >= nobs) break;
-    T J[24];
-    if (DBG & 1) {
-#pragma unroll
-      for (int j = 0; j < 24; j++) J[j] = X[q][j % 3] + C[q][j % 9];
-    } else {
-      jac_block<T>(X[q], C[q], J);
-    }
-    if (b0 + lane < nobs) {
-#pragma unroll
-      for (int j = 0; j < 24; j++) ws[lane * 25 + j] = J[j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int64_t nvalid = (nobs - b0) < 64 ? (nobs - b0) * 24 : 64 * 24;
-    T *out = vals + b0 * 24;
-#pragma unroll
-    for (int it = 0; it < 24 / VEC; it++) {
-      const int e = (it * 64 + lane) * VEC;
-      if (e < nvalid && !((DBG & 2) && ws[0] != (T)12345.678)) {
-        T v[VEC];
-#pragma unroll
-        for (int r = 0; r < VEC; r++) {
-          const int ee = e + r, oo = ee / 24;
-          v[r] = ws[oo * 25 + (ee - oo * 24)];
-        }
-        typedef T vst __attribute__((ext_vector_type(VEC)));
-        vst w;
-#pragma unroll
-        for (int r = 0; r < VEC; r++) w[r] = v[r];
-        // plain 16-byte store.  (An inline-asm `global_store_dwordx4 ... sc1` was tried to keep the stream out of L2: no
-        // speed-up, and without the wait state hipcc inserts after a >64-bit store whose data registers are rewritten it
-        // corrupted 0.5 % of the blocks at 12 M observations -- found by tools/dbg_big.py, hence the plain store.)
-        *reinterpret_cast<vst *>(out + e) = w;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+  if ((nobs & 63) && wid == nfull % nw) {  // the ragged last batch, by the wave whose turn it would have been
+    int pi0, ci0;
+    jac_load_idx<T, DBG>(nfull, lane, nobs, cam0, pnt0, pi0, ci0);
+    jac_gather_point<T, DBG>(pi0, x, X0);
+    jac_issue_cam<T, CDBG>(ci0, lane, cpre, stg);
+    jac_wait_cam<T, 0>(stg);
+    jac_land_cam<T>(stg, lane, ws, P0);
+    jac_emit<T, DBG, false>(X0, P0, ws, lane, nfull * 64, nobs, vals);
   }
 }
 
 }  // namespace
 
 static inline unsigned grid_for(int64_t n, int blk) { return (unsigned)((n + blk - 1) / blk); }
-static inline unsigned jac_grid(int64_t nobs) { return grid_for(nobs, BLK * NBW); }
+// Persistent grid of k_jac_coord: as many workgroups as the device keeps resident (LDS: 3 per CU for double), never
+// more than there are batches of 64 observations.
+template <typename K>
+static unsigned jac_grid(ba_problem *p, K kernel, int64_t nobs) {
+  int per_cu = 0, ncu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu < 1) ncu = 256;
+  if (const char *e = getenv("BA_JAC_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+  const int64_t need = (nobs + 64 * (BLK / 64) - 1) / (64 * (BLK / 64));
+  const int64_t cap = (int64_t)per_cu * ncu;
+  return (unsigned)(need < cap ? need : cap);
+}
 
 int launch_residual_f64(ba_problem *p, const double *d_x, double *d_r, hipStream_t st) {
   if (p->nobs == 0) return BA_OK;
@@ -357,10 +510,10 @@ int launch_jac_coord_f64(ba_problem *p, const double *d_x, double *d_vals, hipSt
   ProfScope ps(p, PC_JAC_COORD, st);
   double *cpad = nullptr;
   BA_CHECK(ba_scratch(p, 3, (size_t)(p->ncams * CPAD + 2) * sizeof(double), (void **)&cpad));
-  hipLaunchKernelGGL(k_pad_cams<double>, dim3(grid_for(p->ncams * CPAD, BLK)), dim3(BLK), 0, st, p->ncams,
-                     d_x + 3 * p->npnts, cpad);
-  hipLaunchKernelGGL(k_jac_coord<double>, dim3(jac_grid(p->nobs)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0,
-                     p->pnt0, d_x, (const double *)cpad, d_vals);
+  hipLaunchKernelGGL(k_cam_pre<double>, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_x + 3 * p->npnts,
+                     cpad);
+  hipLaunchKernelGGL((k_jac_coord<double, 0>), dim3(jac_grid(p, k_jac_coord<double, 0>, p->nobs)), dim3(BLK), 0, st,
+                     p->nobs, p->npnts, p->cam0, p->pnt0, d_x, (const double *)cpad, d_vals);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
@@ -374,13 +527,13 @@ extern "C" int ba_debug_jac_bench(ba_problem *p, const double *d_x, double *d_va
   double *cpad = nullptr;
   BA_CHECK(ba_scratch(p, 3, (size_t)(p->ncams * CPAD + 2) * sizeof(double), (void **)&cpad));
   auto launch = [&]() {
-    dim3 g(jac_grid(p->nobs)), b(BLK);
-    hipLaunchKernelGGL(k_pad_cams<double>, dim3(grid_for(p->ncams * CPAD, BLK)), dim3(BLK), 0, st, p->ncams,
-                       d_x + 3 * p->npnts, cpad);
-#define JV(v) case v: hipLaunchKernelGGL((k_jac_coord<double, v>), g, b, 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_x, (const double *)cpad, d_vals); break;
+    dim3 b(BLK);
+    hipLaunchKernelGGL(k_cam_pre<double>, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_x + 3 * p->npnts,
+                       cpad);
+#define JV(v) case v: hipLaunchKernelGGL((k_jac_coord<double, v>), dim3(jac_grid(p, k_jac_coord<double, v>, p->nobs)), b, 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_x, (const double *)cpad, d_vals); break;
     switch (variant) {
-      JV(1) JV(2) JV(3)
-      default: hipLaunchKernelGGL((k_jac_coord<double, 0>), g, b, 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_x, (const double *)cpad, d_vals);
+      JV(1) JV(2) JV(3) JV(5) JV(13) JV(9) JV(25) JV(41) JV(57) JV(64) JV(77)
+      default: hipLaunchKernelGGL((k_jac_coord<double, 0>), dim3(jac_grid(p, k_jac_coord<double, 0>, p->nobs)), b, 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_x, (const double *)cpad, d_vals);
     }
 #undef JV
   };
@@ -401,10 +554,9 @@ int launch_jac_coord_f32(ba_problem *p, const float *d_x, float *d_vals, hipStre
   ProfScope ps(p, PC_JAC_COORD, st);
   float *cpad = nullptr;
   BA_CHECK(ba_scratch(p, 3, (size_t)(p->ncams * CPAD + 2) * sizeof(double), (void **)&cpad));
-  hipLaunchKernelGGL(k_pad_cams<float>, dim3(grid_for(p->ncams * CPAD, BLK)), dim3(BLK), 0, st, p->ncams,
-                     d_x + 3 * p->npnts, cpad);
-  hipLaunchKernelGGL(k_jac_coord<float>, dim3(jac_grid(p->nobs)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0,
-                     p->pnt0, d_x, (const float *)cpad, d_vals);
+  hipLaunchKernelGGL(k_cam_pre<float>, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_x + 3 * p->npnts, cpad);
+  hipLaunchKernelGGL((k_jac_coord<float, 0>), dim3(jac_grid(p, k_jac_coord<float, 0>, p->nobs)), dim3(BLK), 0, st, p->nobs,
+                     p->npnts, p->cam0, p->pnt0, d_x, (const float *)cpad, d_vals);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }

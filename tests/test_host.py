@@ -103,3 +103,15 @@ def test_partition_by_point(ba, small_prob):
             assert len(arrs[3]) == 3 * arrs[5] + 9 * p["ncams"]
             assert abs(arrs[6] - p["nobs"] / world) <= 0.1 * p["nobs"] + 64
         assert tot == p["nobs"]
+
+
+def test_jac_kernel_inflight_registers_untouched():
+    """k_jac_coord requests its camera rows with inline-asm loads the compiler cannot track; the generated code must
+    not touch their destination registers before the matching inline-asm s_waitcnt (tools/check_jac_isa.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_jac_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
