@@ -63,6 +63,38 @@ constexpr int LDA2 = 130;  // row stride 260 dwords = 4 mod 64: conflict-free MF
 constexpr int XDL = 18;
 constexpr size_t DIAG_LDS_ELEMS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB + 16 * 17);
 
+// broadcast lane `src` (a compile-time constant after unrolling) of v to the whole wave: v_readlane_b32 into SGPRs
+template <typename T>
+__device__ inline T bcast_lane(T v, int src);
+template <>
+__device__ inline double bcast_lane<double>(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+template <>
+__device__ inline float bcast_lane<float>(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// 1 / d on the pivot chain: hardware reciprocal + Newton steps (to a last-bit error of the true quotient; the full IEEE
+// division sequence is ~3x longer and sits 128 times on the tile's critical path).  0 -> inf, as division.
+template <typename T>
+__device__ inline T fast_recip(T d);
+template <>
+__device__ inline double fast_recip<double>(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  if (d != 0.0) {
+    x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+    x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+  }
+  return x;
+}
+template <>
+__device__ inline float fast_recip<float>(float d) {
+  float x = __builtin_amdgcn_rcpf(d);
+  if (d != 0.0f) x = __builtin_fmaf(__builtin_fmaf(-d, x, 1.0f), x, x);
+  return x;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__restrict__ Linv_k,
                                                    T *__restrict__ D_k, int *__restrict__ flag,
@@ -81,7 +113,8 @@ __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__rest
   T *a = sm, *xd = sm + NB * LDA2, *dd = xd + 8 * 16 * XDL, *dinv = dd + NB, *l16 = dinv + NB;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  // tile -> LDS: 16-byte loads, 8 in flight per thread; the strict upper triangle is zeroed
+  // tile -> LDS: 16-byte loads, 8 in flight per thread (unpredicated: loads under a per-thread condition serialise).
+  // The strict upper triangle of the LDS image is never read before the inverse phase writes it.
 #pragma unroll
   for (int b0 = 0; b0 < 4; b0++) {
     d2 v[8];
@@ -90,10 +123,7 @@ __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__rest
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const int idx = 2 * ((b0 * 8 + q) * 256 + tid), i = idx >> 7, j = idx & (NB - 1);
-      d2 w = v[q];
-      if (j > i) w[0] = 0.0;
-      if (j + 1 > i) w[1] = 0.0;
-      *reinterpret_cast<d2 *>(a + i * LDA2 + j) = w;
+      *reinterpret_cast<d2 *>(a + i * LDA2 + j) = v[q];
     }
   }
   for (int idx = tid; idx < 8 * 16 * XDL; idx += 256) xd[idx] = 0.0;
@@ -101,30 +131,43 @@ __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__rest
   STAMP(0)
   for (int jb = 0; jb < 8; jb++) {
     const int o = 16 * jb;
-    {  // unblocked LDL' of the diagonal block, one element per thread (a single-wave variant without the 16
-       // workgroup barriers measured 40 us SLOWER per tile: the LDS round trips of one wave serialise)
-      const int i = tid >> 4, c = tid & 15;
+    if (wv == 0) {
+      // unblocked LDL' of the 16x16 diagonal block in the registers of one wave: lane i holds row i, a pivot and the
+      // pivot column travel by v_readlane (constant lane numbers after unrolling) -- no LDS round trip and no barrier
+      // inside the 16 dependent steps (the LDS version with a workgroup barrier per pivot took 3 us per block).
+      const int i = lane & 15;  // lanes 16..63 shadow lanes 0..15
+      T r[16], invs[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) r[c] = a[(o + i) * LDA2 + o + c];
+      T myd = 0, myinv = 0;
+#pragma unroll
       for (int j = 0; j < 16; j++) {
-        const T d = a[(o + j) * LDA2 + o + j];
-        const T inv = (T)1 / d;
-        if (i > j && c > j && c <= i) a[(o + i) * LDA2 + o + c] -= a[(o + i) * LDA2 + o + j] * inv * a[(o + c) * LDA2 + o + j];
-        if (tid == 0) {
-          dd[o + j] = d;
-          dinv[o + j] = inv;
-          if (d == 0.0) *flag = 1;
+        const T d = bcast_lane<T>(r[j], j);
+        const T inv = fast_recip<T>(d);
+        invs[j] = inv;
+        if (i == j) {
+          myd = d;
+          myinv = inv;
         }
-        __syncthreads();
+        const T t = r[j] * inv;
+#pragma unroll
+        for (int c = j + 1; c < 16; c++) r[c] -= t * bcast_lane<T>(r[j], c);  // rows above the diagonal carry garbage, unused
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          if (c < i) a[(o + i) * LDA2 + o + c] = r[c];             // X = L D stays unscaled in the tile image
+          l16[i * 17 + c] = (c < i) ? r[c] * invs[c] : (T)0;      // scaled copy for the row solves below (broadcast reads)
+        }
+        dd[o + i] = myd;
+        dinv[o + i] = myinv;
+        if (myd == (T)0) *flag = 1;
       }
     }
+    __syncthreads();
     STAMP(1)
     // X = A(:,jb) L16^-T for the rows below the diagonal block by forward substitution, one row per thread (the rows
-    // are independent; X = L D stays unscaled).  L16 (scaled) is first copied to a small array so that every read of it
-    // is a broadcast.
-    if (tid < 256) {
-      const int i = tid >> 4, c = tid & 15;
-      l16[i * 17 + c] = (c < i) ? a[(o + i) * LDA2 + o + c] * dinv[o + c] : 0.0;
-    }
-    __syncthreads();
+    // are independent; X = L D stays unscaled).
     if (tid < NB - o - 16) {
       const int r = o + 16 + tid;
       T xr[16];
@@ -176,9 +219,13 @@ __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__rest
     }
   }
   __syncthreads();
-  // full inverse: X(I,J) = -Linv16(I) * sum_{K=J}^{I-1} L(I,K) X(K,J); X(I,J)[i][j] kept at a[16J+j][16I+i]
-  for (int I = 1; I < 8; I++) {
-    for (int J = wv; J < I; J += 4) {
+  // full inverse: X(I,J) = -Linv16(I) * sum_{K=J}^{I-1} L(I,K) X(K,J); X(I,J)[i][j] kept at a[16J+j][16I+i].  A block
+  // column J of the inverse depends on L and on its own blocks only, so each wave owns whole columns -- {0}, {1,6},
+  // {2,5}, {3,4}: seven blocks each -- and walks down them with wave-local fences, no workgroup barrier.
+  for (int pass = 0; pass < 2; pass++) {
+    const int J = pass == 0 ? wv : 7 - wv;
+    if (pass == 1 && wv == 0) break;  // column 7 has no block below its diagonal
+    for (int I = J + 1; I < 8; I++) {
       d4 acc = {0, 0, 0, 0};
       for (int K = J; K < I; K++) {
 #pragma unroll
@@ -195,31 +242,29 @@ __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__rest
         out = RT<T>::mfma(xd[(I * 16 + fr) * XDL + RT<T>::row(lane, g)], acc[g], out);
 #pragma unroll
       for (int g = 0; g < 4; g++) a[(16 * J + fr) * LDA2 + 16 * I + RT<T>::row(lane, g)] = -out[g];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();
   }
+  __syncthreads();
   STAMP(4)
-  for (int it = 0; it < 32; it++) {  // LDS -> L (scaled, D on the diagonal) and Linv tiles, 16-byte stores
+  // LDS -> Linv tile (lower triangle only: the upper triangle of the buffer is zeroed once, when it is allocated) and D.
+  // The factored diagonal tile itself is not written back: nothing reads it (panel solves and sweeps use Linv and D).
+  for (int it = 0; it < 32; it++) {
     const int idx = 2 * (it * 256 + tid), i = idx >> 7, c0 = idx & (NB - 1);
-    d2 lv, xv;
+    if (c0 > i) continue;
+    d2 xv;
 #pragma unroll
     for (int e = 0; e < 2; e++) {
       const int c = c0 + e;
-      T l, x;
-      if (c < i) {
-        l = a[i * LDA2 + c] * dinv[c];
+      T x;
+      if (c < i)
         x = ((i >> 4) == (c >> 4)) ? xd[((i >> 4) * 16 + (i & 15)) * XDL + (c & 15)] : a[c * LDA2 + i];
-      } else if (c == i) {
-        l = dd[i];  // D on the diagonal of the stored tile (informative only)
-        x = 1.0;
-      } else {
-        l = 0.0;
-        x = 0.0;
-      }
-      lv[e] = l;
+      else
+        x = (c == i) ? (T)1 : (T)0;
       xv[e] = x;
     }
-    *reinterpret_cast<d2 *>(Skk + idx) = lv;
     *reinterpret_cast<d2 *>(Linv_k + idx) = xv;
   }
   if (tid < NB) D_k[tid] = dd[tid];
@@ -795,6 +840,8 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S) {
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_chain, hipEventDisableTiming));
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_bulk, hipEventDisableTiming));
   BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(T)));
+  // k_ldl_diag writes the lower triangle of each inverse only; the consumers read whole tiles
+  BA_HIP_CHECK(hipMemset(w->Linv, 0, (size_t)nt * NB * NB * sizeof(T)));
   BA_HIP_CHECK(hipMalloc((void **)&w->D, (size_t)nt * NB * 2 * sizeof(T)));  // D | y scratch
   BA_HIP_CHECK(hipMalloc((void **)&w->flag, sizeof(int)));
   return set_kernel_attrs<T>();
@@ -1083,6 +1130,7 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
   unsigned long long *st = nullptr;
   BA_HIP_CHECK(hipMalloc((void **)&S, NB * NB * sizeof(double)));
   BA_HIP_CHECK(hipMalloc((void **)&Li, NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMemset(Li, 0, NB * NB * sizeof(double)));
   BA_HIP_CHECK(hipMalloc((void **)&D, NB * sizeof(double)));
   BA_HIP_CHECK(hipMalloc((void **)&flag, sizeof(int)));
   BA_HIP_CHECK(hipMalloc((void **)&st, 6 * sizeof(unsigned long long)));
