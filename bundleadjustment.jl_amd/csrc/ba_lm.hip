@@ -144,6 +144,14 @@ struct LMWorkFull : LMWork {
   DenseLDLT<float> ldl32;
   float *rhs32 = nullptr;
   bool have32 = false, last_f32 = false;
+  // hipGraph replay of the two launch sequences of the LM loop (launch-bound on small problems: LadyBug-49 issues ~60
+  // kernels of a few microseconds per iteration).  x/x_trial and r/r_trial swap on an accepted step, so each sequence
+  // is recorded once per parity of the swap; the damping reaches the recorded kernels through d_lambda.
+  double *d_lambda = nullptr, *h_lambda = nullptr;  // device scalar, pinned staging
+  int *h_flag = nullptr;                            // pinned copy of the pivot flag
+  hipGraphExec_t g_step[2] = {nullptr, nullptr}, g_refresh[2] = {nullptr, nullptr};
+  int g_key = -1;  // normalize + 4 * facto_f32 the step graphs were recorded for
+  int parity = 0;
 };
 
 namespace {
@@ -214,6 +222,9 @@ static int lm_ensure(ba_problem *p) {
   BA_CHECK(dmalloc(&w->s.scal_rep, (int64_t)RP_COUNT));
   BA_HIP_CHECK(hipHostMalloc((void **)&w->s.h_sh, SH_COUNT * sizeof(double)));
   BA_HIP_CHECK(hipHostMalloc((void **)&w->s.h_rp, RP_COUNT * sizeof(double)));
+  BA_HIP_CHECK(hipHostMalloc((void **)&w->h_lambda, sizeof(double)));
+  BA_HIP_CHECK(hipHostMalloc((void **)&w->h_flag, sizeof(int)));
+  BA_CHECK(dmalloc(&w->d_lambda, (int64_t)1));
   BA_CHECK(build_tasks(p, &w->tasks));
   return BA_OK;
 }
@@ -231,6 +242,13 @@ void lm_free(ba_problem *p) {
                   w->tasks.task_a, w->tasks.task_b, w->s.own_red ? w->s.red : nullptr};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
+  for (int q = 0; q < 2; q++) {
+    if (w->g_step[q]) (void)hipGraphExecDestroy(w->g_step[q]);
+    if (w->g_refresh[q]) (void)hipGraphExecDestroy(w->g_refresh[q]);
+  }
+  if (w->d_lambda) (void)hipFree(w->d_lambda);
+  if (w->h_lambda) (void)hipHostFree(w->h_lambda);
+  if (w->h_flag) (void)hipHostFree(w->h_flag);
   if (w->s.h_sh) (void)hipHostFree(w->s.h_sh);
   if (w->s.h_rp) (void)hipHostFree(w->s.h_rp);
   delete w;
@@ -274,18 +292,19 @@ static int fetch_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 
 // delta = -(J'J + lambda I)^-1 J'r at the current linearisation; also |J delta + r|^2 -> SH_MODEL, |delta|^2
 static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, hipStream_t st,
-                       bool facto_f32 = false) {
+                       bool facto_f32 = false, const double *d_lambda = nullptr) {
+  // d_lambda: the damping is read from device memory (recorded launches); `lambda` is then the multiplier 1
   // every rank holds partial Hcc / Schur sums; the lambda I of the camera block is added by rank 0 only
   const double lam_diag = (p->rank == 0) ? lambda : 0.0;
-  BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st));
+  BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, d_lambda));
   BA_CHECK(launch_schur_blocks(p, &w->tasks, w->J, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->n,
-                               p->rank == 0 ? w->npad : w->n, st));
+                               p->rank == 0 ? w->npad : w->n, st, d_lambda));
   BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
   BA_CHECK(launch_schur_rhs(p, w->J, w->r, w->u, w->rhs, st));
   BA_CHECK(comm_sum(p, w, 0, w->s.off_gc, st));  // S tiles and rhs are adjacent
   if (normalize != 0) {  // :J / :A column scaling of the camera system (Hcc must be the global sum: multi-GPU runs
                          // reduce it with gc, see refresh_linearisation)
-    BA_CHECK(launch_cam_scale(p, w->Hcc, normalize == 2 ? lambda : 0.0, w->colscale, st));
+    BA_CHECK(launch_cam_scale(p, w->Hcc, normalize == 2 ? lambda : 0.0, w->colscale, st, d_lambda));
     BA_CHECK(launch_scale_S(p, w->n, w->ldl.nt, w->colscale, w->ldl.S, st));
     BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));
   }
@@ -330,6 +349,91 @@ static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
     ba_set_error("reduced camera system: exactly zero pivot (SQDException in the reference)");
     return BA_ERR_ZERO_PIVOT;
   }
+  return BA_OK;
+}
+
+// ---- recorded launch sequences ------------------------------------------------------------------------------------------
+static bool graphs_allowed(ba_problem *p, LMWorkFull *w) {
+  if (p->prof_on || p->allreduce || w->ldl.side_cus > 0) return false;  // per-kernel events / host hook / forked streams
+  const char *e = getenv("BA_LM_GRAPH");
+  return !(e && e[0] == '0');
+}
+
+template <typename F>
+static int record_graph(hipStream_t st, hipGraphExec_t *out, F body) {
+  hipGraph_t g = nullptr;
+  BA_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+  int rc = body();
+  hipError_t e = hipStreamEndCapture(st, &g);
+  if (rc != BA_OK) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  BA_HIP_CHECK(e);
+  e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  BA_HIP_CHECK(e);
+  return BA_OK;
+}
+
+// one trial step at damping `lambda`: linear solve, model decrease, trial residual, scalars and pivot flag to the host
+static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, bool facto_f32, hipStream_t st) {
+  if (!graphs_allowed(p, w)) {
+    BA_CHECK(linear_step(p, w, lambda, normalize, st, facto_f32));
+    BA_CHECK(step_scalars(p, w, st));
+    BA_CHECK(trial_point(p, w, st));
+    BA_CHECK(comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st));
+    BA_CHECK(fetch_scalars(p, w, st));
+    BA_HIP_CHECK(hipMemcpy(w->h_flag, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost));
+    return BA_OK;
+  }
+  const int key = normalize + 4 * (facto_f32 ? 1 : 0);
+  if (w->g_key != key) {
+    for (int q = 0; q < 2; q++)
+      if (w->g_step[q]) {
+        (void)hipGraphExecDestroy(w->g_step[q]);
+        w->g_step[q] = nullptr;
+      }
+    w->g_key = key;
+  }
+  if (facto_f32) BA_CHECK(ensure_f32(w));  // no allocation while recording
+  hipGraphExec_t &g = w->g_step[w->parity];
+  if (!g) {
+    BA_CHECK(record_graph(st, &g, [&]() -> int {
+      BA_HIP_CHECK(hipMemcpyAsync(w->d_lambda, w->h_lambda, sizeof(double), hipMemcpyHostToDevice, st));
+      BA_CHECK(linear_step(p, w, 1.0, normalize, st, facto_f32, w->d_lambda));
+      BA_CHECK(step_scalars(p, w, st));
+      BA_CHECK(trial_point(p, w, st));
+      BA_HIP_CHECK(hipMemcpyAsync(w->s.h_sh, w->scal, SH_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+      BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+      BA_HIP_CHECK(hipMemcpyAsync(w->h_flag, facto_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      return BA_OK;
+    }));
+  }
+  *w->h_lambda = lambda;
+  w->last_f32 = facto_f32;
+  BA_HIP_CHECK(hipGraphLaunch(g, st));
+  BA_HIP_CHECK(hipStreamSynchronize(st));
+  return BA_OK;
+}
+
+// after an accepted step (x/x_trial, r/r_trial already swapped): J, the normal-equation blocks, J'r, scalars to the host
+static int accept_refresh(ba_problem *p, LMWorkFull *w, hipStream_t st) {
+  if (!graphs_allowed(p, w)) {
+    BA_CHECK(refresh_linearisation(p, w, false, st));
+    return fetch_scalars(p, w, st);
+  }
+  hipGraphExec_t &g = w->g_refresh[w->parity];
+  if (!g) {
+    BA_CHECK(record_graph(st, &g, [&]() -> int {
+      BA_CHECK(refresh_linearisation(p, w, false, st));
+      BA_HIP_CHECK(hipMemcpyAsync(w->s.h_sh, w->scal, SH_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+      BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+      return BA_OK;
+    }));
+  }
+  BA_HIP_CHECK(hipGraphLaunch(g, st));
+  BA_HIP_CHECK(hipStreamSynchronize(st));
   return BA_OK;
 }
 
@@ -451,26 +555,13 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   while (!(small_step || first_order || small_residual || small_obj_change || tired || fail2)) {
     if (V) iter++;                                                                           // lm.jl:127
     if (!V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);  // LevenbergMarquardt.jl:143-147
-    if ((rc = linear_step(p, w, lambda, o->normalize, st, V && o->facto_f32)) != BA_OK) break;
+    if ((rc = trial_step(p, w, lambda, o->normalize, V && o->facto_f32, st)) != BA_OK) break;  // lm.jl:154-254
     stats->n_factor++;
-    if ((rc = step_scalars(p, w, st)) != BA_OK) break;
-    if ((rc = trial_point(p, w, st)) != BA_OK) break;  // lm.jl:251-254
     stats->n_residual++;
-    if ((rc = comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st)) != BA_OK) break;
-    if ((rc = fetch_scalars(p, w, st)) != BA_OK) break;
-    {
-      int h = 0;
-      hipError_t e = hipMemcpy(&h, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost);
-      if (e != hipSuccess) {
-        ba_set_error("pivot flag copy: %s", hipGetErrorString(e));
-        rc = BA_ERR_HIP;
-        break;
-      }
-      if (h) {
-        ba_set_error("reduced camera system: exactly zero pivot (SQDException in the reference)");
-        rc = BA_ERR_ZERO_PIVOT;
-        break;
-      }
+    if (*w->h_flag) {
+      ba_set_error("reduced camera system: exactly zero pivot (SQDException in the reference)");
+      rc = BA_ERR_ZERO_PIVOT;
+      break;
     }
     dr2 = 0.5 * h_sh[SH_MODEL];  // 1/2 |delta_r|^2   (lm.jl:229)
     double obj_suiv = 0.5 * h_sh[SH_RSQ_TRIAL];
@@ -535,12 +626,12 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
       }
       std::swap(w->x, w->x_trial);  // x .= x_suiv
       std::swap(w->r, w->r_trial);  // r .= r_suiv
+      w->parity ^= 1;
       old_obj = obj;
       norm_r = norm_rsuiv;
       obj = obj_suiv;
-      if ((rc = refresh_linearisation(p, w, false, st)) != BA_OK) break;  // J, J'r  (lm.jl:341,370)
+      if ((rc = accept_refresh(p, w, st)) != BA_OK) break;  // J, J'r  (lm.jl:341,370)
       stats->n_jacobian++;
-      if ((rc = fetch_scalars(p, w, st)) != BA_OK) break;
       norm_Jtr = std::sqrt(h_sh[SH_GP] + h_rp[RP_GC]);
       norm_x = std::sqrt(h_sh[SH_X_P] + h_rp[RP_X_C]);
       if (!V) norm_delta = nd;  // LevenbergMarquardt.jl:352

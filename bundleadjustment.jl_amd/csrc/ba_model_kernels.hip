@@ -469,10 +469,22 @@ static inline unsigned grid_for(int64_t n, int blk) { return (unsigned)((n + blk
 // more than there are batches of 64 observations.
 template <typename K>
 static unsigned jac_grid(ba_problem *p, K kernel, int64_t nobs) {
+  // queried once per kernel and device (the launch may be recorded into a hipGraph: no runtime queries there)
+  struct Entry { const void *k; int dev, per_cu, ncu; };
+  static Entry cache[32];
+  static int ncache = 0;
   int per_cu = 0, ncu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu < 1) ncu = 256;
-  if (const char *e = getenv("BA_JAC_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+  for (int q = 0; q < ncache; q++)
+    if (cache[q].k == (const void *)kernel && cache[q].dev == p->device) {
+      per_cu = cache[q].per_cu;
+      ncu = cache[q].ncu;
+    }
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu < 1) ncu = 256;
+    if (const char *e = getenv("BA_JAC_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    if (ncache < 32) cache[ncache++] = Entry{(const void *)kernel, p->device, per_cu, ncu};
+  }
   const int64_t need = (nobs + 64 * (BLK / 64) - 1) / (64 * (BLK / 64));
   const int64_t cap = (int64_t)per_cu * ncu;
   return (unsigned)(need < cap ? need : cap);

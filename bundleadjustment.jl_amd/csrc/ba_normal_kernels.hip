@@ -121,11 +121,14 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_
 }
 
 // ---- per point: U^-1 = (Hpp + lambda I)^-1 (6, symmetric) and u = U^-1 gp -------------------------------------
-__global__ __launch_bounds__(BLK) void k_schur_prep(int64_t npnts, double lambda, const double *__restrict__ Hpp,
-                                                     const double *__restrict__ gp, double *__restrict__ Uinv,
-                                                     double *__restrict__ u) {
+// lam_dev (here and below): when non-null the damping is lambda * lam_dev[0] -- a launch recorded in a hipGraph keeps
+// its arguments, so the replayed LM iteration reads the current damping from device memory.
+__global__ __launch_bounds__(BLK) void k_schur_prep(int64_t npnts, double lambda, const double *__restrict__ lam_dev,
+                                                     const double *__restrict__ Hpp, const double *__restrict__ gp,
+                                                     double *__restrict__ Uinv, double *__restrict__ u) {
   int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x;
   if (p >= npnts) return;
+  if (lam_dev) lambda *= lam_dev[0];
   const double *h = Hpp + 6 * p;
   double a = h[0] + lambda, b = h[1], c = h[2], d = h[3] + lambda, e = h[4], f = h[5] + lambda;
   // cofactors of the symmetric 3x3 [[a b c],[b d e],[c e f]]
@@ -183,8 +186,9 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
                                                        const int *__restrict__ task_a, const int *__restrict__ task_b,
                                                        const double *__restrict__ J, const double *__restrict__ Y,
                                                        const double *__restrict__ Hcc, double lambda,
-                                                       double *__restrict__ S) {
+                                                       const double *__restrict__ lam_dev, double *__restrict__ S) {
   __shared__ double stage[BLK / 64][2][48];
+  if (lam_dev) lambda *= lam_dev[0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4, tl = fk >> 1, al = fk & 1;
   // grid-stride over the keys: the AQL grid size is a 32-bit count of work-items, and Final-13682 has 93.6 M keys
@@ -262,9 +266,10 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
 // columns are eliminated in closed 3x3 form here, so only the camera columns matter: d_j = sqrt(diag(Hcc)_j [+ lambda]),
 // S <- D^-1 S D^-1, rhs <- D^-1 rhs, and afterwards dc <- D^-1 dc'.  Same step in exact arithmetic, better conditioned.
 __global__ __launch_bounds__(BLK) void k_cam_scale(int64_t ncams, const double *__restrict__ Hcc, double add,
-                                                    double *__restrict__ dsc) {
+                                                    const double *__restrict__ lam_dev, double *__restrict__ dsc) {
   int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
   if (i >= 9 * ncams) return;
+  if (lam_dev) add *= lam_dev[0];
   int64_t c = i / 9;
   int j = (int)(i - 9 * c);
   double v = sqrt(Hcc[45 * c + j * (j + 1) / 2 + j] + add);
@@ -421,17 +426,18 @@ int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, doubl
 }
 
 int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const double *d_gp, double *d_Uinv,
-                      double *d_u, hipStream_t st) {
+                      double *d_u, hipStream_t st, const double *d_lambda) {
   if (p->npnts == 0) return BA_OK;
   ProfScope ps(p, PC_SCHUR_PREP, st);
-  hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, lambda, d_Hpp, d_gp,
-                     d_Uinv, d_u);
+  hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, lambda, d_lambda, d_Hpp,
+                     d_gp, d_Uinv, d_u);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
 
 int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
-                        const double *d_Hcc, double lambda, double *d_S, int64_t n, int64_t npad, hipStream_t st) {
+                        const double *d_Hcc, double lambda, double *d_S, int64_t n, int64_t npad, hipStream_t st,
+                        const double *d_lambda) {
   ProfScope ps(p, PC_SCHUR_S, st);
   BA_HIP_CHECK(hipMemsetAsync(d_S, 0, (size_t)dense_ldl_tiles_doubles(n) * sizeof(double), st));
   if (p->nobs > 0)
@@ -440,16 +446,18 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
     int64_t nb = (T->nkeys + BLK / 64 - 1) / (BLK / 64);
     if (nb > (int64_t)1 << 22) nb = (int64_t)1 << 22;  // 2^22 blocks x 256 lanes = 2^30 work-items
     hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nb), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
-                       T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_S);
+                       T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, d_S);
   }
   if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
 
-int launch_cam_scale(ba_problem *p, const double *d_Hcc, double add, double *d_dsc, hipStream_t st) {
+int launch_cam_scale(ba_problem *p, const double *d_Hcc, double add, double *d_dsc, hipStream_t st,
+                     const double *d_lambda) {
   if (p->ncams == 0) return BA_OK;
-  hipLaunchKernelGGL(k_cam_scale, dim3(grid_for(9 * p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_Hcc, add, d_dsc);
+  hipLaunchKernelGGL(k_cam_scale, dim3(grid_for(9 * p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_Hcc, add, d_lambda,
+                     d_dsc);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
