@@ -144,6 +144,9 @@ struct LMWorkFull : LMWork {
   DenseLDLT<float> ldl32;
   float *rhs32 = nullptr;
   bool have32 = false, last_f32 = false;
+  // eltype(x) = Float32 runs (BALNLPModel(file, Float32), src/BALNLPModels.jl:91): x, r and J are produced by the Float32
+  // kernels and widened; every iterate is rounded to Float32.  Buffers allocated on first use.
+  float *xf = nullptr, *rf = nullptr, *Jf = nullptr;
   // hipGraph replay of the two launch sequences of the LM loop (launch-bound on small problems: LadyBug-49 issues ~60
   // kernels of a few microseconds per iteration).  x/x_trial and r/r_trial swap on an accepted step, so each sequence
   // is recorded once per parity of the swap; the damping reaches the recorded kernels through d_lambda.
@@ -169,6 +172,14 @@ int launch_convert(const A *in, B *out, int64_t n, hipStream_t st) {
   return BA_OK;
 }
 }  // namespace
+
+static int ensure_xf32(ba_problem *p, LMWorkFull *w) {
+  if (w->xf) return BA_OK;
+  BA_HIP_CHECK(hipMalloc((void **)&w->xf, (size_t)(w->nvar > 0 ? w->nvar : 1) * sizeof(float)));
+  BA_HIP_CHECK(hipMalloc((void **)&w->rf, (size_t)(w->nequ > 0 ? w->nequ : 1) * sizeof(float)));
+  BA_HIP_CHECK(hipMalloc((void **)&w->Jf, (size_t)(p->nobs > 0 ? 24 * p->nobs : 1) * sizeof(float)));
+  return BA_OK;
+}
 
 static int ensure_f32(LMWorkFull *w) {
   if (w->have32) return BA_OK;
@@ -237,6 +248,9 @@ void lm_free(ba_problem *p) {
     dense_ldl_free(&w->ldl32);
     (void)hipFree(w->rhs32);
   }
+  if (w->xf) (void)hipFree(w->xf);
+  if (w->rf) (void)hipFree(w->rf);
+  if (w->Jf) (void)hipFree(w->Jf);
   void *ptrs[] = {w->x, w->x_trial, w->delta, w->r, w->r_trial, w->J, w->Hpp, w->gp, w->Uinv, w->u, w->Hcc,
                   w->partial, w->colscale, w->Yobs, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
                   w->tasks.task_a, w->tasks.task_b, w->s.own_red ? w->s.red : nullptr};
@@ -268,10 +282,23 @@ static int comm_sum(ba_problem *p, LMWorkFull *w, int64_t off, int64_t count, hi
 }
 
 // r, J and the normal-equation blocks at w->x; fills sharded/replicated scalars RSQ?, GP, GC, X_P, X_C
-static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too, hipStream_t st) {
-  if (residual_too) BA_CHECK(launch_residual_f64(p, w->x, w->r, st));
+static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too, hipStream_t st, bool xf32 = false) {
+  if (xf32) {  // w->x holds Float32 values: evaluate with the Float32 kernels, widen (exact)
+    BA_CHECK(launch_convert(w->x, w->xf, w->nvar, st));
+    if (residual_too) {
+      BA_CHECK(launch_residual_f32(p, w->xf, w->rf, st));
+      BA_CHECK(launch_convert(w->rf, w->r, w->nequ, st));
+    }
+  } else if (residual_too) {
+    BA_CHECK(launch_residual_f64(p, w->x, w->r, st));
+  }
   BA_CHECK(launch_sumsq(p, w->nequ, w->r, w->partial, w->scal, SH_RSQ, st));
-  BA_CHECK(launch_jac_coord_f64(p, w->x, w->J, st));
+  if (xf32) {
+    BA_CHECK(launch_jac_coord_f32(p, w->xf, w->Jf, st));
+    BA_CHECK(launch_convert(w->Jf, w->J, 24 * p->nobs, st));
+  } else {
+    BA_CHECK(launch_jac_coord_f64(p, w->x, w->J, st));
+  }
   BA_CHECK(launch_point_blocks(p, w->J, w->r, w->Hpp, w->gp, st));
   BA_CHECK(launch_cam_blocks(p, w->J, w->r, w->Hcc, w->gc, st));
   BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->gp, w->partial, w->scal, SH_GP, st));
@@ -334,9 +361,16 @@ static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st) {
   return BA_OK;
 }
 
-static int trial_point(ba_problem *p, LMWorkFull *w, hipStream_t st) {
+static int trial_point(ba_problem *p, LMWorkFull *w, hipStream_t st, bool xf32 = false) {
   BA_CHECK(launch_axpy(p, w->nvar, w->x, w->delta, w->x_trial, st));
-  BA_CHECK(launch_residual_f64(p, w->x_trial, w->r_trial, st));
+  if (xf32) {  // x_suiv is a Float32 vector in the reference: round, evaluate in Float32
+    BA_CHECK(launch_convert(w->x_trial, w->xf, w->nvar, st));
+    BA_CHECK(launch_convert(w->xf, w->x_trial, w->nvar, st));
+    BA_CHECK(launch_residual_f32(p, w->xf, w->rf, st));
+    BA_CHECK(launch_convert(w->rf, w->r_trial, w->nequ, st));
+  } else {
+    BA_CHECK(launch_residual_f64(p, w->x_trial, w->r_trial, st));
+  }
   BA_CHECK(launch_sumsq(p, w->nequ, w->r_trial, w->partial, w->scal, SH_RSQ_TRIAL, st));
   return BA_OK;
 }
@@ -377,23 +411,24 @@ static int record_graph(hipStream_t st, hipGraphExec_t *out, F body) {
 }
 
 // one trial step at damping `lambda`: linear solve, model decrease, trial residual, scalars and pivot flag to the host
-static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, bool facto_f32, hipStream_t st) {
+static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, bool facto_f32, bool xf32,
+                      hipStream_t st) {
   if (!graphs_allowed(p, w)) {
     BA_CHECK(linear_step(p, w, lambda, normalize, st, facto_f32));
     BA_CHECK(step_scalars(p, w, st));
-    BA_CHECK(trial_point(p, w, st));
+    BA_CHECK(trial_point(p, w, st, xf32));
     BA_CHECK(comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st));
     BA_CHECK(fetch_scalars(p, w, st));
     BA_HIP_CHECK(hipMemcpy(w->h_flag, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost));
     return BA_OK;
   }
-  const int key = normalize + 4 * (facto_f32 ? 1 : 0);
+  const int key = normalize + 4 * (facto_f32 ? 1 : 0) + 8 * (xf32 ? 1 : 0);
   if (w->g_key != key) {
-    for (int q = 0; q < 2; q++)
-      if (w->g_step[q]) {
-        (void)hipGraphExecDestroy(w->g_step[q]);
-        w->g_step[q] = nullptr;
-      }
+    for (int q = 0; q < 2; q++) {
+      if (w->g_step[q]) (void)hipGraphExecDestroy(w->g_step[q]);
+      if (w->g_refresh[q]) (void)hipGraphExecDestroy(w->g_refresh[q]);
+      w->g_step[q] = w->g_refresh[q] = nullptr;
+    }
     w->g_key = key;
   }
   if (facto_f32) BA_CHECK(ensure_f32(w));  // no allocation while recording
@@ -403,7 +438,7 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
       BA_HIP_CHECK(hipMemcpyAsync(w->d_lambda, w->h_lambda, sizeof(double), hipMemcpyHostToDevice, st));
       BA_CHECK(linear_step(p, w, 1.0, normalize, st, facto_f32, w->d_lambda));
       BA_CHECK(step_scalars(p, w, st));
-      BA_CHECK(trial_point(p, w, st));
+      BA_CHECK(trial_point(p, w, st, xf32));
       BA_HIP_CHECK(hipMemcpyAsync(w->s.h_sh, w->scal, SH_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
       BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
       BA_HIP_CHECK(hipMemcpyAsync(w->h_flag, facto_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -418,15 +453,15 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
 }
 
 // after an accepted step (x/x_trial, r/r_trial already swapped): J, the normal-equation blocks, J'r, scalars to the host
-static int accept_refresh(ba_problem *p, LMWorkFull *w, hipStream_t st) {
+static int accept_refresh(ba_problem *p, LMWorkFull *w, bool xf32, hipStream_t st) {
   if (!graphs_allowed(p, w)) {
-    BA_CHECK(refresh_linearisation(p, w, false, st));
+    BA_CHECK(refresh_linearisation(p, w, false, st, xf32));
     return fetch_scalars(p, w, st);
   }
   hipGraphExec_t &g = w->g_refresh[w->parity];
   if (!g) {
     BA_CHECK(record_graph(st, &g, [&]() -> int {
-      BA_CHECK(refresh_linearisation(p, w, false, st));
+      BA_CHECK(refresh_linearisation(p, w, false, st, xf32));
       BA_HIP_CHECK(hipMemcpyAsync(w->s.h_sh, w->scal, SH_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
       BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
       return BA_OK;
@@ -504,6 +539,10 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     ba_set_error("ba_lm_solve: normalize must be 0 (:None), 1 (:J) or 2 (:A)");
     return BA_ERR_ARG;
   }
+  if (o->x_f32 && p->world > 1) {
+    ba_set_error("ba_lm_solve: eltype(x) = Float32 runs are single-GPU only for now");
+    return BA_ERR_ARG;
+  }
   if (o->normalize != 0 && p->world > 1) {
     ba_set_error("ba_lm_solve: normalize != :None is single-GPU only for now (Hcc is not all-reduced)");
     return BA_ERR_ARG;
@@ -515,7 +554,9 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   hipStream_t st = p->stream;
   const int V = o->variant;
   // defaults: src/lm.jl:20-26 / src/LevenbergMarquardt.jl:21-26
-  const double eps = 2.220446049250313e-16, sq = std::sqrt(eps), cbr = std::pow(eps, 1.0 / 3.0);
+  const bool xf32 = o->x_f32 != 0;  // eltype(x) = Float32: eps(T)-derived defaults, Float32 iterates and evaluations
+  if (xf32) BA_CHECK(ensure_xf32(p, w));
+  const double eps = xf32 ? 1.1920928955078125e-07 : 2.220446049250313e-16, sq = std::sqrt(eps), cbr = std::pow(eps, 1.0 / 3.0);
   const double restol = o->restol >= 0 ? o->restol : (V ? cbr : 100 * sq);
   const double satol = o->satol >= 0 ? o->satol : sq, srtol = o->srtol >= 0 ? o->srtol : sq;
   const double oatol = o->oatol >= 0 ? o->oatol : sq, ortol = o->ortol >= 0 ? o->ortol : (V ? cbr : 1000 * sq);
@@ -531,7 +572,11 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   double *h_sh = w->s.h_sh, *h_rp = w->s.h_rp;
 
   BA_HIP_CHECK(hipMemcpyAsync(w->x, x_inout, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
-  BA_CHECK(refresh_linearisation(p, w, true, st));  // r, J, J'r   (lm.jl:39-58)
+  if (xf32) {  // x0 is a Float32 vector at the reference's boundary; make sure of it
+    BA_CHECK(launch_convert(w->x, w->xf, w->nvar, st));
+    BA_CHECK(launch_convert(w->xf, w->x, w->nvar, st));
+  }
+  BA_CHECK(refresh_linearisation(p, w, true, st, xf32));  // r, J, J'r   (lm.jl:39-58)
   BA_CHECK(fetch_scalars(p, w, st));
   stats->n_residual++;
   stats->n_jacobian++;
@@ -555,7 +600,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   while (!(small_step || first_order || small_residual || small_obj_change || tired || fail2)) {
     if (V) iter++;                                                                           // lm.jl:127
     if (!V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);  // LevenbergMarquardt.jl:143-147
-    if ((rc = trial_step(p, w, lambda, o->normalize, V && o->facto_f32, st)) != BA_OK) break;  // lm.jl:154-254
+    if ((rc = trial_step(p, w, lambda, o->normalize, V && o->facto_f32, xf32, st)) != BA_OK) break;  // lm.jl:154-254
     stats->n_factor++;
     stats->n_residual++;
     if (*w->h_flag) {
@@ -578,7 +623,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
         // delta /= delta_d ; delta_r = (delta_r - r)/delta_d (lm.jl:277) is again -(J delta + r) for the new delta
         if ((rc = launch_scale_scalar(p, w->nvar, w->delta, 1.0 / delta_d, st)) != BA_OK) break;
         if ((rc = step_scalars(p, w, st)) != BA_OK) break;
-        if ((rc = trial_point(p, w, st)) != BA_OK) break;
+        if ((rc = trial_point(p, w, st, xf32)) != BA_OK) break;
         stats->n_residual++;
         if ((rc = comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st)) != BA_OK) break;
         if ((rc = fetch_scalars(p, w, st)) != BA_OK) break;
@@ -630,7 +675,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
       old_obj = obj;
       norm_r = norm_rsuiv;
       obj = obj_suiv;
-      if ((rc = accept_refresh(p, w, st)) != BA_OK) break;  // J, J'r  (lm.jl:341,370)
+      if ((rc = accept_refresh(p, w, xf32, st)) != BA_OK) break;  // J, J'r  (lm.jl:341,370)
       stats->n_jacobian++;
       norm_Jtr = std::sqrt(h_sh[SH_GP] + h_rp[RP_GC]);
       norm_x = std::sqrt(h_sh[SH_X_P] + h_rp[RP_X_C]);

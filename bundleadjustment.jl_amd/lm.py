@@ -65,15 +65,15 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
     nlp = model.nlp if isinstance(model, FeasibilityResidual) else model
     if not isinstance(nlp, BALNLPModel):
         raise TypeError("model must be a FeasibilityResidual(BALNLPModel) or a BALNLPModel")
-    if nlp.T is not np.float64:
-        raise NotImplementedError("the device LM iterates in Float64 (eltype(x) = Float32 runs are not implemented)")
+    xf32 = nlp.T is np.float32  # eltype(x) = Float32: facto_type defaults to it (lm.jl:20), eps(T) tolerances
     variant = 0 if linesearch is None else 1
     if variant == 0 and (facto_type is not None or max_time is not None):
         raise TypeError("LevenbergMarquardt.jl's Levenberg_Marquardt has no facto_type / max_time keyword")
     x0 = np.array(nlp.meta.x0 if x is None else x, dtype=np.float64, copy=True)
     if x0.shape != (nlp.meta.nvar,):
         raise ValueError("x has the wrong length")
-    f32 = facto_type is not None and np.dtype(facto_type) == np.float32
+    f32 = (facto_type is None and xf32 and variant == 1) or \
+        (facto_type is not None and np.dtype(facto_type) == np.float32)
     if facto_type is not None and np.dtype(facto_type) not in (np.dtype(np.float64), np.dtype(np.float32)):
         raise NotImplementedError("facto_type must be Float64 or Float32 (the Float16 path of lm.jl:165-169 is experimental "
                                   "in the reference and not provided)")
@@ -82,7 +82,7 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
         return -1.0 if v is None else float(v)
 
     o = _lib.LMOpts(variant=variant, facto=_FACTO[facto], normalize=_NORM[normalize], linesearch=int(bool(linesearch)),
-                    facto_f32=int(f32), ite_max=-1 if ite_max is None else int(ite_max), verbose=int(verbose), reserved0=0,
+                    facto_f32=int(f32), ite_max=-1 if ite_max is None else int(ite_max), verbose=int(verbose), x_f32=int(xf32),
                     restol=d(restol), satol=d(satol), srtol=d(srtol), oatol=d(oatol), ortol=d(ortol), atol=d(atol),
                     rtol=d(rtol), nu_d=d(nu_d), nu_m=d(nu_m), lam=d(lam), delta_d=d(delta_d), max_time=d(max_time))
     st = _lib.LMStats()
@@ -97,7 +97,7 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
     nlp.counters.neval_residual += st.n_residual
     nlp.counters.neval_jac += st.n_jacobian + 1  # + jac_structure! (src/BALNLPModels.jl:126)
     nlp.counters.neval_jac_residual += st.n_jacobian
-    out = GenericExecutionStats(status=_lib.STATUS[st.status], solution=x0, objective=st.objective, iter=st.iter,
+    out = GenericExecutionStats(status=_lib.STATUS[st.status], solution=x0.astype(nlp.T) if xf32 else x0, objective=st.objective, iter=st.iter,
                                 elapsed_time=st.elapsed_s, loop_time=st.loop_s, n_accepted=st.n_accepted,
                                 n_rejected=st.n_rejected, n_residual=st.n_residual, n_jacobian=st.n_jacobian,
                                 n_factor=st.n_factor, lambda_final=st.lambda_final, log=rows)

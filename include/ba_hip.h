@@ -122,7 +122,8 @@ typedef struct ba_lm_opts {
   int facto_f32;  /* lm.jl only: facto_type = Float32 (src/lm.jl:170-173, src/diffprecsions.jl:39-41) */
   int ite_max;    /* <0: default (200 / 100) */
   int verbose;    /* 1: print the reference's log columns to stderr */
-  int reserved0;
+  int x_f32;      /* 1: eltype(x) = Float32 (a BALNLPModel(file, Float32) run): iterates rounded to Float32, residual and
+                   *    Jacobian by the Float32 kernels, eps(Float32)-derived default tolerances; x_inout stays double */
   double restol, satol, srtol, oatol, ortol, atol, rtol; /* <0: default */
   double nu_d, nu_m, lambda, delta_d;                    /* <=0: default (3, 3, 30 | 0.1, 2) */
   double max_time;                                        /* <=0: 3600 (inert in the reference, lm.jl:33,115,382) */

@@ -267,6 +267,37 @@ def test_lm_facto_f32(ba, orc, small_prob, gpu_ok):
     m.close()
 
 
+def test_lm_float32_model(ba, small_prob, gpu_ok):
+    """BALNLPModel(file, Float32) through Levenberg_Marquardt (eltype(x) = Float32, facto_type defaults to Float32,
+    eps(Float32) tolerances -- lm.jl:20-26).  No reference fixture pins a Float32 run (parity unpinned); checked here:
+    Float32 iterates, and the same minimum as the Float64 run to Float32-level accuracy."""
+    p = small_prob
+    arrays = list(ba.synthetic.as_arrays(p))
+    arrays32 = [arrays[0], arrays[1], arrays[2].astype(np.float32), arrays[3].astype(np.float32)] + arrays[4:]
+    m32 = ba.BALNLPModel(arrays=tuple(arrays32), T=np.float32)
+    m64 = ba.BALNLPModel(arrays=tuple(arrays))
+    # tolerances of the reference's own Float32 experiment (src/diffprecsions.jl:22): with the eps(Float32)-derived
+    # defaults the step test satol + srtol |x| = 3.5e-4 (1 + |x|) stops a BAL problem (|x| ~ 1e4) at the first accepted step
+    tol32 = dict(oatol=1e-4, ortol=1e-4, atol=1e-4, rtol=1e-5, satol=1e-6, srtol=1e-7)
+    st_def = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), "LDL", "AMD", "None", False)
+    assert st_def.status == "small_step" and st_def.iter <= 2
+    st32 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), "LDL", "AMD", "None", False, **tol32)
+    st64 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m64), "LDL", "AMD", "None", False)
+    print("T=Float32:", st32.status, st32.iter, st32.objective, " T=Float64:", st64.status, st64.iter, st64.objective)
+    assert st32.solution.dtype == np.float32
+    assert st32.status in ("first_order", "small_residual", "acceptable", "small_step")
+    assert abs(st32.objective - st64.objective) <= 2e-3 * st64.objective
+    # the returned objective is the one of the returned (Float32) point, evaluated by the Float32 residual kernel
+    r = m32.cons(st32.solution)
+    assert abs(0.5 * float(r.astype(np.float64) @ r.astype(np.float64)) - st32.objective) <= 1e-5 * st32.objective
+    st32b = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), "LDL", "AMD", "None", **tol32)  # LevenbergMarquardt.jl variant
+    print("old variant, T=Float32:", st32b.status, st32b.iter, st32b.objective)
+    st64b = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m64), "LDL", "AMD", "None", **tol32)
+    assert abs(st32b.objective - st64b.objective) <= 2e-3 * st64b.objective
+    m32.close()
+    m64.close()
+
+
 def test_lm_linesearch_vs_oracle(ba, orc, small_prob, gpu_ok):
     p = small_prob
     m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
