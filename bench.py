@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3   # FP32 matrix peak (v_mfma_f32_16x16x4_f32: twice the f64 rate)
 MFMA_F64_PEAK_TF = 78.6    # MI355X FP64 matrix peak (vendor sheet; v_mfma_f64_16x16x4_f64, 2048 flop / 64 clk / SIMD)
 
 
@@ -53,6 +54,8 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only; invalid as a result)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--facto-type", choices=["f64", "f32"], default="f64",
+                    help="facto_type of lm.jl (f32 = the diffprecsions.jl path, BASELINE config 5); the default line is f64")
     ap.add_argument("--backend", default=os.environ.get("BA_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend: nccl (= RCCL, default) or gloo (host-staged all-reduce; rehearsal only)")
     ap.add_argument("--single-device", action="store_true",
@@ -60,14 +63,21 @@ def parse():
     return ap.parse_args()
 
 
+FACTO_TYPE = None  # set from --facto-type
+
+
 def lm_fixed_iterations(ba, fr, k, x=None):
     """exactly k iterations of lm.jl: every stopping test disabled except the iteration cap"""
     return ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False, x=x, ite_max=k - 1, restol=0.0, satol=0.0, srtol=0.0,
-                                  oatol=0.0, ortol=0.0, atol=0.0, rtol=0.0, log=False)
+                                  oatol=0.0, ortol=0.0, atol=0.0, rtol=0.0, log=False, facto_type=FACTO_TYPE)
 
 
 def main():
+    global FACTO_TYPE
     args = parse()
+    if args.facto_type == "f32":
+        import numpy as _np
+        FACTO_TYPE = _np.float32
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,8 +180,9 @@ def main():
             tiles = sum((nt - k - 4) * (nt - k - 3) // 2 for k in range(0, nt - 2, 2) if nt - k - 4 > 0)
             flops = n_fact * tiles * 2 * 2.0 * 128 ** 3
             ach = flops / (ms * 1e-3) / 1e12
-            roof = dict(kernel=name, bound="mfma", achieved=ach, peak=MFMA_F64_PEAK_TF, unit="TFLOP/s",
-                        frac=ach / MFMA_F64_PEAK_TF, traffic=pmc_traffic(args.workload, name),
+            peak_tf = MFMA_F64_PEAK_TF if args.facto_type == "f64" else MFMA_F32_PEAK_TF
+            roof = dict(kernel=name, bound="mfma", achieved=ach, peak=peak_tf, unit="TFLOP/s",
+                        frac=ach / peak_tf, traffic=pmc_traffic(args.workload, name),
                         avg_launch_ms=ms / calls, launches=calls, flops_per_launch=flops / calls)
         else:
             roof = dict(kernel=name, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None,
@@ -225,10 +236,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if args.facto_type == "f64" else "f64 (reduced camera system factored in f32)",
             "data": "synthetic",
             "config": {"workload": f"{args.workload} shape: ncams={ncams} npnts={npnts_g} nobs={nobs_g}, seed "
-                                   f"{ba.synthetic.BASE_SEED}, lm.jl variant, LDL/None, fixed {args.steps} iterations"
+                                   f"{ba.synthetic.BASE_SEED}, lm.jl variant, LDL/None, facto_type {args.facto_type}, fixed {args.steps} iterations"
                                    + ("" if args.scale == 1.0 else f" SCALED x{args.scale} (debug)"),
                        "parallelism": f"points sharded over {world} rank(s), cameras replicated"},
             "jacobian_mnnz_per_s": jac_mnnz,
