@@ -101,3 +101,113 @@ def test_jac_coord_nan_to_zero(orc):
     x = np.array([0.1, 0.2, 0.0, 0, 0, 0.3, 0, 0, 0.0, 1e-7, 1e-12, 500.0])  # rotation about z keeps P1.z = t_z = 0 exactly
     v = orc.jac_coord(cam, cam, x, 1)
     assert np.all(v == 0)
+
+
+# ---- test/runtests.jl:29-128: the reference's own checks of lma_aux.jl / qr_aux.jl, replayed on the oracle ---------------
+def _dense(colptr, rowval, nzval, m, n):
+    A = np.zeros((m, n))
+    for j in range(n):
+        for p in range(colptr[j], colptr[j + 1]):
+            A[rowval[p], j] += nzval[p]
+    return A
+
+
+def _rand_half(rng, k):  # rand(-4.5:4.5, k): the ten half-integers -4.5 ... 4.5
+    return rng.integers(0, 10, k) - 4.5
+
+
+def test_runtests_normalize_qr(orc):
+    """runtests.jl:31-63: normalize_qr_a!, normalize_qr_j!, denormalize_qr! on A = [random 7x5 ; sqrt(lambda) I]."""
+    L = orc.lib()
+    for seed in range(20):
+        rng = np.random.default_rng(seed)
+        m, n, lam = 7, 5, 1.5
+        rows = np.concatenate([rng.integers(1, m + 1, 8), np.arange(m + 1, m + n + 1)]).astype(np.int64)
+        cols = np.concatenate([rng.integers(1, n + 1, 8), np.arange(1, n + 1)]).astype(np.int64)
+        vals = np.concatenate([_rand_half(rng, 8), np.full(n, np.sqrt(lam))])
+        colptr, rowval, nz0 = orc.sparse(rows, cols, vals, m + n, n)
+        A0 = _dense(colptr, rowval, nz0, m + n, n)
+        nz = nz0.copy()
+        cn = np.zeros(n)
+        L.orc_normalize_qr_a(colptr, nz, cn, n)
+        A = _dense(colptr, rowval, nz, m + n, n)
+        for j in range(n):
+            assert abs(np.linalg.norm(A[:, j]) - 1) < 1e-10
+            assert abs(cn[j] - np.linalg.norm(A0[:, j])) < 1e-10
+        L.orc_denormalize_qr(colptr, nz, cn, n)
+        assert np.linalg.norm(_dense(colptr, rowval, nz, m + n, n) - A0) < 1e-10
+        nz = nz0.copy()
+        L.orc_normalize_qr_j(colptr, nz, cn, n)
+        A = _dense(colptr, rowval, nz, m + n, n)
+        for j in range(n):
+            if cn[j] != 0:
+                assert abs(np.linalg.norm(A[:m, j]) - 1) < 1e-10
+                assert A[m + j, j] - A0[m + j, j] / cn[j] < 1e-10
+            assert abs(cn[j] - np.linalg.norm(A0[:m, j])) < 1e-10
+        L.orc_denormalize_qr(colptr, nz, cn, n)
+        assert np.linalg.norm(_dense(colptr, rowval, nz, m + n, n)[:m] - A0[:m]) < 1e-10
+
+
+def test_runtests_normalize_ldl(orc):
+    """runtests.jl:65-88: normalize_ldl!, denormalize_ldl! on the upper triangle of [[I A12];[A12' -lambda I]]."""
+    L = orc.lib()
+    for seed in range(20):
+        rng = np.random.default_rng(100 + seed)
+        m, n, lam = 7, 5, 1.5
+        rows = np.concatenate([np.arange(1, m + 1), rng.integers(1, m + 1, 8), np.arange(m + 1, m + n + 1)]).astype(np.int64)
+        cols = np.concatenate([np.arange(1, m + 1), m + rng.integers(1, n + 1, 8), np.arange(m + 1, m + n + 1)]).astype(np.int64)
+        vals = np.concatenate([np.ones(m), _rand_half(rng, 8), np.full(n, -lam)])
+        colptr, rowval, nz0 = orc.sparse(rows, cols, vals, m + n, m + n)
+        A0 = _dense(colptr, rowval, nz0, m + n, m + n)
+        nz = nz0.copy()
+        cn = np.zeros(n)
+        L.orc_normalize_ldl(colptr, nz, cn, n, m)
+        A = _dense(colptr, rowval, nz, m + n, m + n)
+        for j in range(n):
+            if cn[j] != 0:
+                assert abs(np.linalg.norm(A[:m, m + j]) - 1) < 1e-10
+                assert abs(A[m + j, m + j] - A0[m + j, m + j] / cn[j] ** 2) < 1e-10
+            assert abs(cn[j] - np.linalg.norm(A0[:m, m + j])) < 1e-10  # (the reference's slice m+1:m+j is a typo for m+j)
+        L.orc_denormalize_ldl(colptr, nz, cn, n, m)
+        assert np.linalg.norm(_dense(colptr, rowval, nz, m + n, m + n)[:m, m:] - A0[:m, m:]) < 1e-10
+
+
+def test_runtests_mul_sparse(orc):
+    """runtests.jl:91-108: COO spmv (duplicates add up, as sparse() sums them) against A * x."""
+    for seed in range(20):
+        rng = np.random.default_rng(200 + seed)
+        m, n, nnz = 7, 5, 8
+        rows = rng.integers(1, m + 1, nnz).astype(np.int64)
+        cols = rng.integers(1, n + 1, nnz).astype(np.int64)
+        vals = _rand_half(rng, nnz)
+        A = np.zeros((m, n))
+        np.add.at(A, (rows - 1, cols - 1), vals)
+        for _ in range(2):
+            x = _rand_half(rng, n)
+            assert np.linalg.norm(orc.mul_sparse(rows, cols, vals, x, m) - A @ x) < 1e-10
+
+
+def test_runtests_least_squares_solve(orc):
+    """runtests.jl:111-128 pins the :QR branch (SuiteSparse SPQR, absent here) by x = A \\ b for A = [J; sqrt(lambda) I].
+    The build serves :QR and :LDL with one solve of the same normal equations; the oracle's LDL' of the augmented matrix
+    [[I J];[J' -lambda I]] with right-hand side [b1; -sqrt(lambda) b2] is that solve, checked against lstsq."""
+    for seed in range(20):
+        rng = np.random.default_rng(300 + seed)
+        m, n, lam = 7, 5, 1.5
+        rj = rng.integers(1, m + 1, 8).astype(np.int64)
+        cj = rng.integers(1, n + 1, 8).astype(np.int64)
+        vj = _rand_half(rng, 8)
+        b = _rand_half(rng, m + n)
+        J = np.zeros((m, n))
+        np.add.at(J, (rj - 1, cj - 1), vj)
+        A = np.vstack([J, np.sqrt(lam) * np.eye(n)])
+        true_x = np.linalg.lstsq(A, b, rcond=None)[0]
+        # upper triangle of K, columns: m identity columns, then [J(:,j); -lambda]
+        rows = np.concatenate([np.arange(1, m + 1), rj, np.arange(m + 1, m + n + 1)]).astype(np.int64)
+        cols = np.concatenate([np.arange(1, m + 1), m + cj, np.arange(m + 1, m + n + 1)]).astype(np.int64)
+        vals = np.concatenate([np.ones(m), vj, np.full(n, -lam)])
+        colptr, rowval, nzval = orc.sparse(rows, cols, vals, m + n, m + n)
+        rhs = np.concatenate([b[:m], -np.sqrt(lam) * b[m:]])
+        rc, x, lnz, D = orc.ldl_solve(colptr, rowval, nzval, np.arange(m + n, dtype=np.int64), rhs)
+        assert rc == 0
+        assert np.linalg.norm(x[m:] - true_x) < 1e-10
