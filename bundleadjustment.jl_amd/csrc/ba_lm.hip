@@ -153,8 +153,9 @@ struct LMWorkFull : LMWork {
   double *d_lambda = nullptr, *h_lambda = nullptr;  // device scalar, pinned staging
   int *h_flag = nullptr;                            // pinned copy of the pivot flag
   hipGraphExec_t g_step[2] = {nullptr, nullptr}, g_refresh[2] = {nullptr, nullptr};
-  int g_key = -1;  // normalize + 4 * facto_f32 the step graphs were recorded for
+  int g_key = -1;  // normalize + 4 * facto_f32 + 8 * x_f32 the graphs were recorded for
   int parity = 0;
+  bool g_off = false;  // a recording failed on this handle: plain launches from then on
 };
 
 namespace {
@@ -388,7 +389,7 @@ static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 
 // ---- recorded launch sequences ------------------------------------------------------------------------------------------
 static bool graphs_allowed(ba_problem *p, LMWorkFull *w) {
-  if (p->prof_on || p->allreduce || w->ldl.side_cus > 0) return false;  // per-kernel events / host hook / forked streams
+  if (w->g_off || p->prof_on || p->allreduce || w->ldl.side_cus > 0) return false;  // per-kernel events / host hook / forked streams
   const char *e = getenv("BA_LM_GRAPH");
   return !(e && e[0] == '0');
 }
@@ -434,7 +435,7 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
   if (facto_f32) BA_CHECK(ensure_f32(w));  // no allocation while recording
   hipGraphExec_t &g = w->g_step[w->parity];
   if (!g) {
-    BA_CHECK(record_graph(st, &g, [&]() -> int {
+    const int grc = record_graph(st, &g, [&]() -> int {
       BA_HIP_CHECK(hipMemcpyAsync(w->d_lambda, w->h_lambda, sizeof(double), hipMemcpyHostToDevice, st));
       BA_CHECK(linear_step(p, w, 1.0, normalize, st, facto_f32, w->d_lambda));
       BA_CHECK(step_scalars(p, w, st));
@@ -443,7 +444,13 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
       BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
       BA_HIP_CHECK(hipMemcpyAsync(w->h_flag, facto_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
       return BA_OK;
-    }));
+    });
+    if (grc != BA_OK) {  // recording is an optimisation: without it the same launches are issued one by one
+      (void)hipGetLastError();
+      g = nullptr;
+      w->g_off = true;
+      return trial_step(p, w, lambda, normalize, facto_f32, xf32, st);
+    }
   }
   *w->h_lambda = lambda;
   w->last_f32 = facto_f32;
@@ -460,12 +467,18 @@ static int accept_refresh(ba_problem *p, LMWorkFull *w, bool xf32, hipStream_t s
   }
   hipGraphExec_t &g = w->g_refresh[w->parity];
   if (!g) {
-    BA_CHECK(record_graph(st, &g, [&]() -> int {
+    const int grc = record_graph(st, &g, [&]() -> int {
       BA_CHECK(refresh_linearisation(p, w, false, st, xf32));
       BA_HIP_CHECK(hipMemcpyAsync(w->s.h_sh, w->scal, SH_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
       BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
       return BA_OK;
-    }));
+    });
+    if (grc != BA_OK) {
+      (void)hipGetLastError();
+      g = nullptr;
+      w->g_off = true;
+      return accept_refresh(p, w, xf32, st);
+    }
   }
   BA_HIP_CHECK(hipGraphLaunch(g, st));
   BA_HIP_CHECK(hipStreamSynchronize(st));
