@@ -175,9 +175,9 @@ def main():
         n_fact = max(1, prof["k_ldl_diag"][1] // max(1, (9 * ncams + 127) // 128))
         if name == "k_ldl_update":
             # one launch per panel pair (k, k+1), k even: S_ij -= V0_i L_jk' + V1_i L_j,k+1' for the m(m+1)/2 lower tiles
-            # right of tile column k+3, m = nt-k-4: 2 tile products of 2*128^3 flop each (kernel table)
+            # right of tile column k+1, m = nt-k-2: 2 tile products of 2*128^3 flop each (kernel table)
             nt = (9 * ncams + 127) // 128
-            tiles = sum((nt - k - 4) * (nt - k - 3) // 2 for k in range(0, nt - 2, 2) if nt - k - 4 > 0)
+            tiles = sum((nt - k - 2) * (nt - k - 1) // 2 for k in range(0, nt - 2, 2) if nt - k - 2 > 0)
             flops = n_fact * tiles * 2 * 2.0 * 128 ** 3
             ach = flops / (ms * 1e-3) / 1e12
             peak_tf = MFMA_F64_PEAK_TF if args.facto_type == "f64" else MFMA_F32_PEAK_TF

@@ -961,8 +961,12 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
       BA_HIP_CHECK(hipStreamWaitEvent(sb, w->ev_chain, 0));
       if (k > 0) BA_HIP_CHECK(hipStreamWaitEvent(ss, w->ev_bulk, 0));  // previous bulk update finished
     }
-    launch_pair(p, w, k, k + 2, true, V0, V1, ss);   // tile columns k+2, k+3: what the next panels need
-    launch_pair(p, w, k, k + 4, false, V0, V1, sb);  // the rest
+    if (forked || getenv("BA_LDL_SPLIT_PAIR")) {
+      launch_pair(p, w, k, k + 2, true, V0, V1, ss);   // tile columns k+2, k+3: what the next panels need
+      launch_pair(p, w, k, k + 4, false, V0, V1, sb);  // the rest
+    } else {
+      launch_pair(p, w, k, k + 2, false, V0, V1, st);  // one stream: the whole trailing matrix in one launch
+    }
     if (forked) BA_HIP_CHECK(hipEventRecord(w->ev_bulk, sb));
     // next chain: panels k+2, k+3
     launch_diag(p, w, k + 2, ss);
