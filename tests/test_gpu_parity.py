@@ -309,6 +309,24 @@ def test_lm_linesearch_vs_oracle(ba, orc, small_prob, gpu_ok):
     m.close()
 
 
+def test_lm_step_dubrovnik_shape_vs_oracle(ba, orc, gpu_ok):
+    """BASELINE config 3's shape (Dubrovnik-356-226730: 1.26 M observations, n = 3204, 26 tile rows): one LM step against
+    the oracle's LDL' of the augmented system (~40 s of single-threaded CPU factorisation, the largest size the oracle
+    finishes in a test).  Tolerance: SURVEY 8d, |delta - delta_ref| <= 1e-9 |delta_ref|."""
+    p = ba.synthetic.make_named("dubrovnik-356")
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    lam = 30.0
+    d, half, jtr = ba.lm_step(m, p["x0"], lam)
+    rc, d_ref, dr_ref, jtr_ref = orc.lm_step(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"], lam)
+    assert rc == 0
+    rel = np.linalg.norm(d - d_ref) / np.linalg.norm(d_ref)
+    print(f"dubrovnik shape: |d - d_ref|/|d_ref| = {rel:.2e}, |d| = {np.linalg.norm(d_ref):.3e}")
+    assert rel <= 1e-9
+    assert abs(half - 0.5 * dr_ref @ dr_ref) <= 1e-9 * (0.5 * dr_ref @ dr_ref)
+    assert np.max(np.abs(jtr - jtr_ref)) <= 1e-11 * np.max(np.abs(jtr_ref))
+    m.close()
+
+
 def test_many_cameras_step(ba, orc, gpu_ok):
     """Wide reduced camera system (600 cameras -> n = 5400, 43 tile rows) with few points: exercises the tile indexing
     of the Schur scatter, the paired-panel factorisation and the sweeps well beyond the other tests' sizes.  Reference:
