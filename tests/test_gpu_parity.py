@@ -402,3 +402,30 @@ def test_full_size_properties(ba, gpu_ok):
     lhs = d @ m.jtprod_coo(vals, w)
     assert abs(lhs - fd @ w) <= 1e-5 * (np.linalg.norm(fd) * np.linalg.norm(w))
     m.close()
+
+
+def test_lm_step_venice_size_normal_equations(ba, gpu_ok):
+    """The metric's own size (Venice-1778 shape: 5.0 M observations, 120 M non-zeros, n = 16 002): the step returned by
+    ba_lm_step must solve the reference's linear system, checked matrix-free with the Jacobian taken through the C ABI
+    (jac_structure! / jac_coord!) -- (J'J + lambda I) delta = -J'r (lm.jl:154-238 in normal-equation form) and
+    1/2 |J delta + r|^2 = the returned model value (lm.jl:229)."""
+    import scipy.sparse as sp
+    p = ba.synthetic.make_named("venice-1778")
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    lam = 30.0
+    d, half, jtr = ba.lm_step(m, p["x0"], lam)
+    rows, cols = m.jac_structure()
+    vals = m.jac_coord(p["x0"])
+    r = m.cons(p["x0"])
+    J = sp.csr_matrix((vals, (rows - 1, cols - 1)), shape=(m.meta.ncon, m.meta.nvar))
+    del rows, cols, vals
+    g = J.T @ r
+    assert np.max(np.abs(jtr - g)) <= 1e-11 * np.max(np.abs(g))
+    Jd = J @ d
+    lhs = J.T @ Jd + lam * d
+    rel = np.linalg.norm(lhs + g) / np.linalg.norm(g)
+    print(f"venice size: |(J'J + lam I) d + J'r| / |J'r| = {rel:.2e}")
+    assert rel <= 1e-9
+    model = 0.5 * float((Jd + r) @ (Jd + r))
+    assert abs(half - model) <= 1e-10 * model
+    m.close()
