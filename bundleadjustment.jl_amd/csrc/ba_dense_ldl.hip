@@ -98,10 +98,30 @@ __device__ inline float fast_recip<float>(float d) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__restrict__ Linv_k,
                                                    T *__restrict__ D_k, int *__restrict__ flag,
-                                                   unsigned long long *__restrict__ stamps) {
+                                                   unsigned long long *__restrict__ stamps,
+                                                   const int *__restrict__ wait_ready) {
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *sm = reinterpret_cast<T *>(smraw);
+  if (wait_ready) {
+    // Hoisted launch: this workgroup was started early (while CUs were free) and waits here until the trailing update
+    // running beside it has finished this tile (k_ldl_update, tile 0, release at agent scope).  Bounded: after ~2 s of
+    // polling it gives up and reports through the pivot flag, so the wave always reaches its exit.
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+      int seen = 0;
+      for (unsigned n = 0; n < (1u << 20); n++) {
+        seen = __hip_atomic_load(wait_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen) break;
+        __builtin_amdgcn_s_sleep(64);
+      }
+      ok = seen;
+      if (!seen) *flag = 2;
+    }
+    __syncthreads();
+    if (!ok) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every thread: the tile's lines are re-read from memory
+  }
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;  // diagnostic phase timers (stamps != null only)
 #define STAMP(slot)                                        \
   if (stamps) {                                            \
@@ -623,7 +643,7 @@ __global__ __launch_bounds__(256) void k_ldl_pair2_rs(T *__restrict__ S, const T
 template <typename T, int MODE, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const T *__restrict__ V0,
                                                         const T *__restrict__ V1, int k, int base, int nt,
-                                                        int nblk) {
+                                                        int nblk, int *__restrict__ ready) {
   BA_VT
   static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -684,6 +704,11 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
           if (NT_C) __builtin_nontemporal_store(nv, &cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)]);
           else cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)] = nv;
         }
+  }
+  if (ready && i == base && j == base) {  // the next diagonal tile is final: tell the workgroup waiting to factor it
+    __threadfence();                        // every thread's stores, agent scope (written back past this XCD's L2)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -844,6 +869,9 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S) {
   BA_HIP_CHECK(hipMemset(w->Linv, 0, (size_t)nt * NB * NB * sizeof(T)));
   BA_HIP_CHECK(hipMalloc((void **)&w->D, (size_t)nt * NB * 2 * sizeof(T)));  // D | y scratch
   BA_HIP_CHECK(hipMalloc((void **)&w->flag, sizeof(int)));
+  BA_HIP_CHECK(hipMalloc((void **)&w->ready, (size_t)nt * sizeof(int)));
+  BA_HIP_CHECK(hipStreamCreateWithFlags(&w->hoist, hipStreamNonBlocking));
+  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_top, hipEventDisableTiming));
   return set_kernel_attrs<T>();
 }
 
@@ -856,16 +884,20 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->flag) (void)hipFree(w->flag);
   if (w->side) (void)hipStreamDestroy(w->side);
   if (w->bulk) (void)hipStreamDestroy(w->bulk);
+  if (w->ready) (void)hipFree(w->ready);
+  if (w->hoist) (void)hipStreamDestroy(w->hoist);
+  if (w->ev_top) (void)hipEventDestroy(w->ev_top);
   if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
   if (w->ev_bulk) (void)hipEventDestroy(w->ev_bulk);
   *w = DenseLDLT<T>();
 }
 
 template <typename T>
-static int launch_diag(ba_problem *p, DenseLDLT<T> *w, int k, hipStream_t st) {
+static int launch_diag(ba_problem *p, DenseLDLT<T> *w, int k, hipStream_t st, const int *wait_ready = nullptr) {
   ProfScope ps(p, PC_LDL_DIAG, st);
   hipLaunchKernelGGL(k_ldl_diag<T>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(T), st, w->S + tile_index(k, k) * NB * NB,
-                     w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag, (unsigned long long *)nullptr);
+                     w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag, (unsigned long long *)nullptr,
+                     wait_ready);
   return BA_OK;
 }
 
@@ -901,7 +933,7 @@ static int launch_col(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0, hipStr
 // pair update of the tile columns >= base with panels k, k+1 (first2: only columns base and base+1)
 template <typename T>
 static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, bool first2, const T *V0, const T *V1,
-                       hipStream_t st) {
+                       hipStream_t st, int *ready = nullptr) {
   const int nt = (int)w->nt, m = nt - base;
   if (m <= 0) return BA_OK;
   ProfScope ps(p, first2 ? PC_LDL_SYRK : PC_LDL_UPDATE, st);
@@ -910,7 +942,7 @@ static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, bool fir
     hipLaunchKernelGGL(k_ldl_pair2_rs<T>, dim3(4 * nblk), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, V0, V1, k, base, nt);
   } else {
     const int nblk = m * (m + 1) / 2;
-    hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st, w->S, V0, V1, k, base, nt, nblk);
+    hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st, w->S, V0, V1, k, base, nt, nblk, ready);
   }
   return BA_OK;
 }
@@ -937,6 +969,43 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
     BA_HIP_CHECK(hipStreamWaitEvent(ss, w->ev_bulk, 0));
     BA_HIP_CHECK(hipStreamWaitEvent(sb, w->ev_bulk, 0));
   }
+  // Hoisted diagonal tile (default on for nt >= HOIST_MIN_TILES + 2, BA_LDL_HOIST=0 disables): the kernel that factors
+  // tile (k+2, k+2) is LAUNCHED at the top of pair (k, k+1) on a second stream -- while CUs are free; once the trailing
+  // update fills the GPU a 153 KB-LDS workgroup finds no CU -- and waits in place for the flag the trailing update's
+  // first workgroup raises when that tile is final.  It then factors the tile beside the rest of the update: one 59 us
+  // diagonal kernel per pair leaves the critical path.  Nothing throughput-bound is moved, no CU mask is involved (a
+  // CU-masked bulk stream measured 42 / 46 / 59 ms with 1 / 2 / 4 CUs masked off, against 37 ms unmasked).
+  constexpr int HOIST_MIN_TILES = 32;
+  static const bool hoist_off = [] { const char *e = getenv("BA_LDL_HOIST"); return e && e[0] == '0'; }();
+  w->hoisting = !p->prof_on && !can_overlap && !hoist_off && nt >= HOIST_MIN_TILES + 2;
+  if (w->hoisting) {
+    BA_HIP_CHECK(hipMemsetAsync(w->ready, 0, (size_t)nt * sizeof(int), st));
+    // one fork for the whole factorisation: the hoisted kernels only depend on their flags (and on stream order among
+    // themselves); each gets its CU in the idle gaps of the panel chain before the trailing update it waits for starts
+    BA_HIP_CHECK(hipEventRecord(w->ev_top, st));
+    BA_HIP_CHECK(hipStreamWaitEvent(w->hoist, w->ev_top, 0));
+    launch_diag(p, w, 0, st);
+    for (int k = 0, q = 0; k < nt; k += 2, q ^= 1) {
+      T *V0 = Vs[q][0], *V1 = Vs[q][1];
+      const bool hoist = (k + 2 < nt) && (nt - k - 2 >= HOIST_MIN_TILES);
+      if (hoist) {  // the next pair's first diagonal kernel: waits in place for ready[k+2]
+        launch_diag(p, w, k + 2, w->hoist, w->ready + k + 2);
+        BA_HIP_CHECK(hipEventRecord(w->ev_chain, w->hoist));
+      }
+      launch_trsm(p, w, k, V0, d_b, st);  // diag(k) is done: prologue, hoisted, or the tail branch below
+      if (k + 1 < nt) {
+        launch_col(p, w, k, V0, st);
+        launch_diag(p, w, k + 1, st);
+        launch_trsm(p, w, k + 1, V1, d_b, st);
+      }
+      if (k + 2 >= nt) break;
+      launch_pair(p, w, k, k + 2, false, V0, V1, st, hoist ? w->ready + k + 2 : nullptr);
+      if (hoist)
+        BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));  // join: Linv / D of tile k+2 are written
+      else
+        launch_diag(p, w, k + 2, st);
+    }
+  } else {
   bool forked = can_overlap;
   // prologue chain: panels 0 and 1
   launch_diag(p, w, 0, ss);
@@ -983,6 +1052,7 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
     BA_HIP_CHECK(hipEventRecord(w->ev_bulk, sb));
     BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_bulk, 0));
   }
+  }  // schedules
   BA_HIP_CHECK(hipGetLastError());
   if (zero_pivot) {
     int h = 0;
@@ -1100,11 +1170,11 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   auto launch = [&]() {
     const double *V0 = V, *V1 = V + (size_t)nt * NB * NB;
     switch (variant) {
-      case 1: hipLaunchKernelGGL((k_ldl_update<double, 1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk); break;
-      case 2: hipLaunchKernelGGL((k_ldl_update<double, 1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk); break;
-      case 8: hipLaunchKernelGGL((k_ldl_update<double, 1, 8>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk); break;
-      case 9: hipLaunchKernelGGL((k_ldl_update<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk); break;
-      default: hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk);
+      case 1: hipLaunchKernelGGL((k_ldl_update<double, 1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 2: hipLaunchKernelGGL((k_ldl_update<double, 1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 8: hipLaunchKernelGGL((k_ldl_update<double, 1, 8>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 9: hipLaunchKernelGGL((k_ldl_update<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      default: hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr);
     }
   };
   {
@@ -1148,7 +1218,7 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
   for (int rep = 0; rep < 3; rep++) {
     BA_HIP_CHECK(hipMemcpy(S, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
     BA_HIP_CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(double), 0, S, Li, D, flag, rep == 2 ? st : nullptr);
+    hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(double), 0, S, Li, D, flag, rep == 2 ? st : nullptr, (const int *)nullptr);
     BA_HIP_CHECK(hipEventRecord(e1, 0));
     BA_HIP_CHECK(hipEventSynchronize(e1));
     if (rep == 1) BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));

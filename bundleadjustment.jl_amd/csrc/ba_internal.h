@@ -65,7 +65,11 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   T *V = nullptr;          // 4 x nt tiles: V_i = L_ik * D_k of two panel pairs (double-buffered for the look-ahead)
   T *Linv = nullptr;       // nt tiles: inverse of each unit-lower diagonal tile
   T *D = nullptr;          // nt*NB pivots (+ nt*NB scratch)
-  int *flag = nullptr;     // device int: set to 1 on an exactly zero pivot
+  int *flag = nullptr;     // device int: set to 1 on an exactly zero pivot (2: a hoisted diagonal tile never became ready)
+  int *ready = nullptr;    // nt device ints: tile (k,k) has received its last trailing update (hoisted-diagonal schedule)
+  hipStream_t hoist = nullptr;   // second stream of the hoisted-diagonal schedule (no CU mask)
+  hipEvent_t ev_top = nullptr;
+  bool hoisting = false;         // the factorisation forks onto `hoist` (set by dense_ldl_factor's schedule choice)
   bool own_S = true;
   hipStream_t side = nullptr, bulk = nullptr;      // look-ahead: panel chain / bulk update streams (disjoint CU masks)
   int side_cus = 0;                                 // 0: no CU-masked streams, factorisation runs on one stream

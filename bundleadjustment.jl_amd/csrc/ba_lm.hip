@@ -389,7 +389,10 @@ static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 
 // ---- recorded launch sequences ------------------------------------------------------------------------------------------
 static bool graphs_allowed(ba_problem *p, LMWorkFull *w) {
-  if (w->g_off || p->prof_on || p->allreduce || w->ldl.side_cus > 0) return false;  // per-kernel events / host hook / forked streams
+  if (w->g_off || p->prof_on || p->allreduce || w->ldl.side_cus > 0) return false;  // events / host hook / forked streams
+  // the hoisted-diagonal schedule of large factorisations has a kernel wait for a flag raised by a kernel running
+  // beside it: only with real streams is that concurrency certain (and the graphs gain nothing at that size)
+  if (w->ldl.nt >= 34) return false;  // = HOIST_MIN_TILES + 2 of dense_ldl_factor
   const char *e = getenv("BA_LM_GRAPH");
   return !(e && e[0] == '0');
 }
@@ -616,6 +619,11 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     if ((rc = trial_step(p, w, lambda, o->normalize, V && o->facto_f32, xf32, st)) != BA_OK) break;  // lm.jl:154-254
     stats->n_factor++;
     stats->n_residual++;
+    if (*w->h_flag == 2) {
+      ba_set_error("dense factorisation: a hoisted diagonal tile never became ready (internal scheduling error)");
+      rc = BA_ERR_HIP;
+      break;
+    }
     if (*w->h_flag) {
       ba_set_error("reduced camera system: exactly zero pivot (SQDException in the reference)");
       rc = BA_ERR_ZERO_PIVOT;
