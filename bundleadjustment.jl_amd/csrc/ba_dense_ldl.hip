@@ -105,12 +105,13 @@ __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__rest
   T *sm = reinterpret_cast<T *>(smraw);
   if (wait_ready) {
     // Hoisted launch: this workgroup was started early (while CUs were free) and waits here until the trailing update
-    // running beside it has finished this tile (k_ldl_update, tile 0, release at agent scope).  Bounded: after ~2 s of
+    // running beside it has finished this tile (k_ldl_update, tile 0, release at agent scope).  Bounded: after ~0.5 s of
     // polling it gives up and reports through the pivot flag, so the wave always reaches its exit.
     __shared__ int ok;
     if (threadIdx.x == 0) {
       int seen = 0;
-      for (unsigned n = 0; n < (1u << 20); n++) {
+      const bool abandoned = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2;  // an earlier tile gave up
+      for (unsigned n = 0; n < (1u << 18) && !abandoned; n++) {
         seen = __hip_atomic_load(wait_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if (seen) break;
         __builtin_amdgcn_s_sleep(64);
@@ -977,7 +978,7 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
   // CU-masked bulk stream measured 42 / 46 / 59 ms with 1 / 2 / 4 CUs masked off, against 37 ms unmasked).
   constexpr int HOIST_MIN_TILES = 32;
   static const bool hoist_off = [] { const char *e = getenv("BA_LDL_HOIST"); return e && e[0] == '0'; }();
-  w->hoisting = !p->prof_on && !can_overlap && !hoist_off && nt >= HOIST_MIN_TILES + 2;
+  w->hoisting = !p->prof_on && !can_overlap && !hoist_off && !w->hoist_disabled && nt >= HOIST_MIN_TILES + 2;
   if (w->hoisting) {
     BA_HIP_CHECK(hipMemsetAsync(w->ready, 0, (size_t)nt * sizeof(int), st));
     // one fork for the whole factorisation: the hoisted kernels only depend on their flags (and on stream order among
@@ -1111,13 +1112,20 @@ static int dense_solve_host(int device, int64_t n, const double *a_lower_rowmajo
   BA_HIP_CHECK(hipEventCreate(&e0));
   BA_HIP_CHECK(hipEventCreate(&e1));
   int zp = 0;
-  BA_HIP_CHECK(hipEventRecord(e0, st));
   const bool fused = getenv("BA_LDL_SEPARATE_FORWARD") == nullptr;
-  rc = dense_ldl_factor<T>(&tmp, &w, st, nullptr, fused ? d_b : nullptr);
-  BA_HIP_CHECK(hipEventRecord(e1, st));
-  if (rc == BA_OK) rc = dense_ldl_solve<T>(&tmp, &w, d_b, st, fused);
-  BA_HIP_CHECK(hipMemcpy(&zp, w.flag, sizeof(int), hipMemcpyDeviceToHost));
-  BA_HIP_CHECK(hipDeviceSynchronize());
+  for (int attempt = 0; attempt < 2; attempt++) {
+    BA_HIP_CHECK(hipEventRecord(e0, st));
+    rc = dense_ldl_factor<T>(&tmp, &w, st, nullptr, fused ? d_b : nullptr);
+    BA_HIP_CHECK(hipEventRecord(e1, st));
+    if (rc == BA_OK) rc = dense_ldl_solve<T>(&tmp, &w, d_b, st, fused);
+    BA_HIP_CHECK(hipMemcpy(&zp, w.flag, sizeof(int), hipMemcpyDeviceToHost));
+    BA_HIP_CHECK(hipDeviceSynchronize());
+    if (zp != 2 || w.hoist_disabled) break;
+    // a hoisted diagonal kernel gave up waiting (kernels serialised, e.g. under a counter-collecting profiler): redo in order
+    w.hoist_disabled = true;
+    BA_HIP_CHECK(hipMemcpy(w.S, tiles.data(), tiles.size() * sizeof(T), hipMemcpyHostToDevice));
+    BA_HIP_CHECK(hipMemcpy(d_b, bb.data(), (size_t)npad * sizeof(T), hipMemcpyHostToDevice));
+  }
   float ms = 0;
   BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   if (factor_ms) *factor_ms = ms;

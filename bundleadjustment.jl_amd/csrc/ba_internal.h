@@ -69,6 +69,7 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   int *ready = nullptr;    // nt device ints: tile (k,k) has received its last trailing update (hoisted-diagonal schedule)
   hipStream_t hoist = nullptr;   // second stream of the hoisted-diagonal schedule (no CU mask)
   hipEvent_t ev_top = nullptr;
+  bool hoist_disabled = false;   // a hoisted kernel once timed out (kernels serialised by a profiler): never again on this handle
   bool hoisting = false;         // the factorisation forks onto `hoist` (set by dense_ldl_factor's schedule choice)
   bool own_S = true;
   hipStream_t side = nullptr, bulk = nullptr;      // look-ahead: panel chain / bulk update streams (disjoint CU masks)

@@ -380,6 +380,10 @@ static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
   int h = 0;
   BA_HIP_CHECK(hipMemcpyAsync(&h, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
   BA_HIP_CHECK(hipStreamSynchronize(st));
+  if (h == 2) {
+    ba_set_error("dense factorisation: a hoisted diagonal tile never became ready (internal scheduling error)");
+    return BA_ERR_HIP;
+  }
   if (h) {
     ba_set_error("reduced camera system: exactly zero pivot (SQDException in the reference)");
     return BA_ERR_ZERO_PIVOT;
@@ -414,6 +418,15 @@ static int record_graph(hipStream_t st, hipGraphExec_t *out, F body) {
   return BA_OK;
 }
 
+// A hoisted diagonal kernel of the dense factorisation gave up waiting for its flag: the kernels were not running side by
+// side (a counter-collecting profiler serialises them).  Switch the handle to the in-order schedule; the caller redoes
+// the step (S was consumed by the abandoned factorisation).
+static bool hoist_gave_up(LMWorkFull *w) {
+  if (*w->h_flag != 2 || (w->ldl.hoist_disabled && w->ldl32.hoist_disabled)) return false;
+  w->ldl.hoist_disabled = w->ldl32.hoist_disabled = true;
+  return true;
+}
+
 // one trial step at damping `lambda`: linear solve, model decrease, trial residual, scalars and pivot flag to the host
 static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, bool facto_f32, bool xf32,
                       hipStream_t st) {
@@ -424,6 +437,7 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
     BA_CHECK(comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st));
     BA_CHECK(fetch_scalars(p, w, st));
     BA_HIP_CHECK(hipMemcpy(w->h_flag, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (hoist_gave_up(w)) return trial_step(p, w, lambda, normalize, facto_f32, xf32, st);
     return BA_OK;
   }
   const int key = normalize + 4 * (facto_f32 ? 1 : 0) + 8 * (xf32 ? 1 : 0);
@@ -459,7 +473,7 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
   w->last_f32 = facto_f32;
   BA_HIP_CHECK(hipGraphLaunch(g, st));
   BA_HIP_CHECK(hipStreamSynchronize(st));
-  return BA_OK;
+  return BA_OK;  // (recorded sequences never hoist: graphs_allowed)
 }
 
 // after an accepted step (x/x_trial, r/r_trial already swapped): J, the normal-equation blocks, J'r, scalars to the host
@@ -527,6 +541,11 @@ extern "C" int ba_lm_step(ba_problem *p, const double *x, double lambda, double 
   BA_HIP_CHECK(hipMemcpyAsync(w->x, x, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
   BA_CHECK(refresh_linearisation(p, w, true, st));
   BA_CHECK(linear_step(p, w, lambda, 0, st));
+  {  // same fallback as the LM loop: a hoisted diagonal kernel that gave up -> in-order schedule, redo the step
+    BA_HIP_CHECK(hipMemcpyAsync(w->h_flag, w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    BA_HIP_CHECK(hipStreamSynchronize(st));
+    if (hoist_gave_up(w)) BA_CHECK(linear_step(p, w, lambda, 0, st));
+  }
   BA_CHECK(check_pivot(p, w, st));
   BA_CHECK(step_scalars(p, w, st));
   BA_CHECK(comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st));
