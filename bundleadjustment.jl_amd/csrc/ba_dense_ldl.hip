@@ -10,8 +10,8 @@
 //   k_ldl_diag     : one workgroup factors tile (k,k) in LDS (L_kk, D_k) and forms L_kk^-1 explicitly;
 //   k_ldl_trsm_rs  : X_i = S_ik L_kk^-T (= L_ik D_k) as an MFMA product with L_kk^-1 (32 rows per workgroup), stores
 //                    V_i = X_i and L_ik = X_i D_k^-1; the forward substitution of the right-hand side rides along;
-//   k_ldl_col_rs / k_ldl_pair2_rs : the updates the NEXT panels need (one / two tile columns);
-//   k_ldl_update<1>: S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' for the rest, two panels per pass (v_mfma_f64_16x16x4_f64):
+//   k_ldl_col_rs   : the update of the next tile column, which the second panel of the pair needs;
+//   k_ldl_update<1>: S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' for everything right of the pair, two panels per pass (v_mfma_f64_16x16x4_f64):
 //                    the n^3/3 flops.
 // Solves: forward substitution fused into the panel solves, diagonal scaling folded into the backward sweep by tile rows.
 #include "ba_internal.h"
@@ -602,39 +602,6 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const T *
   }
 }
 
-// rows [32 rq, 32 rq + 32) of S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' for the two tile columns j = base, base+1 (what the
-// next two panels need first).  grid = 4 (2m - 1), m = nt - base: tiles (base+t, base) for t < m, then (base+1+t', base+1)
-template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_pair2_rs(T *__restrict__ S, const T *__restrict__ V0,
-                                                       const T *__restrict__ V1, int k, int base, int nt) {
-  BA_VT
-  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-  T *lds = reinterpret_cast<T *>(smraw);
-  T *sA = lds, *sB = lds + RS * LDK;
-  const int m = nt - base, t = blockIdx.x >> 2, r0 = (blockIdx.x & 3) * RS;
-  const int i = t < m ? base + t : base + 1 + (t - m), j = t < m ? base : base + 1;
-  typename RT<T>::v4 acc[2][2];
-#pragma unroll
-  for (int mm = 0; mm < 2; mm++)
-#pragma unroll
-    for (int n = 0; n < 2; n++) acc[mm][n] = (d4){0, 0, 0, 0};
-  tile_gemm_rows<T, false, 2>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(j, k) * NB * NB, sA, sB, acc, nullptr, nullptr,
-                           V1 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(j, k + 1) * NB * NB);
-  const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) * 32;
-  T *Sij = S + tile_index(i, j) * NB * NB + r0 * NB;
-#pragma unroll
-  for (int n = 0; n < 2; n++) {
-    const int col = wc + 16 * n + (lane & 15);
-#pragma unroll
-    for (int mm = 0; mm < 2; mm++)
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int row = 16 * mm + RT<T>::row(lane, g);
-        Sij[row * NB + col] -= acc[mm][n][g];
-      }
-  }
-}
-
 // Bulk trailing update, two panels per pass:  S_ij -= V0_i L_jk' + V1_i L_{j,k+1}'  for the lower-triangular tile pairs
 // base <= j <= i (K = 256): the trailing matrix is read and written once per TWO panels, which halves its HBM traffic per
 // flop.  (MODE is kept as a template parameter for the micro-benchmark variants; only MODE 1 exists.)
@@ -828,43 +795,7 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S) {
     w->own_S = true;
   }
   BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(T)));  // 2 x two panels of L*D
-  {
-    // Look-ahead needs the latency-bound panel chain to run BESIDE the bulk update.  Its GEMM-shaped kernels only need
-    // workgroup slots as they free up, so they go to a HIGH-PRIORITY stream; the one-workgroup diagonal-tile kernel needs a
-    // whole CU's LDS, which the bulk update (2 workgroups and all 512 registers per SIMD on every CU) never leaves free,
-    // so the bulk stream's CU mask excludes `side_cus` CUs (BA_LDL_SIDE_CUS).  Measured on Venice (n = 16002): 39.0 ms
-    // without look-ahead, 40-51 ms with 2-16 reserved CUs (and 41.7 vs 42.3 ms for the earlier 32-CU two-mask variant):
-    // the panel chain is short enough after the row-split kernels that the partition costs more than it hides, so the
-    // default is OFF (0) and the whole factorisation runs on the caller's stream.
-    int side_cus = 0;
-    if (const char *e = getenv("BA_LDL_SIDE_CUS")) side_cus = atoi(e);
-    hipDeviceProp_t prop;
-    int dev = 0;
-    BA_HIP_CHECK(hipGetDevice(&dev));
-    BA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    const int ncu = prop.multiProcessorCount;
-    w->side_cus = 0;
-    if (side_cus > 0 && side_cus < ncu && ncu <= 1024) {
-      uint32_t m_bulk[32] = {0};
-      const int stride = ncu / side_cus;
-      int cnt = 0;
-      for (int c = 0; c < ncu; c++) {
-        const bool s_ = (c % stride == 0) && cnt < side_cus;
-        if (s_) cnt++;
-        else m_bulk[c / 32] |= 1u << (c % 32);
-      }
-      const uint32_t words = (uint32_t)((ncu + 31) / 32);
-      int pr_lo = 0, pr_hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
-      if (hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, pr_hi) == hipSuccess &&
-          hipExtStreamCreateWithCUMask(&w->bulk, words, m_bulk) == hipSuccess)
-        w->side_cus = cnt;
-      else
-        (void)hipGetLastError();
-    }
-  }
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_chain, hipEventDisableTiming));
-  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_bulk, hipEventDisableTiming));
   BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(T)));
   // k_ldl_diag writes the lower triangle of each inverse only; the consumers read whole tiles
   BA_HIP_CHECK(hipMemset(w->Linv, 0, (size_t)nt * NB * NB * sizeof(T)));
@@ -883,13 +814,10 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->Linv) (void)hipFree(w->Linv);
   if (w->D) (void)hipFree(w->D);
   if (w->flag) (void)hipFree(w->flag);
-  if (w->side) (void)hipStreamDestroy(w->side);
-  if (w->bulk) (void)hipStreamDestroy(w->bulk);
   if (w->ready) (void)hipFree(w->ready);
   if (w->hoist) (void)hipStreamDestroy(w->hoist);
   if (w->ev_top) (void)hipEventDestroy(w->ev_top);
   if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
-  if (w->ev_bulk) (void)hipEventDestroy(w->ev_bulk);
   *w = DenseLDLT<T>();
 }
 
@@ -931,129 +859,68 @@ static int launch_col(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0, hipStr
   return BA_OK;
 }
 
-// pair update of the tile columns >= base with panels k, k+1 (first2: only columns base and base+1)
+// pair update of the lower tiles (i, j), base <= j <= i, with panels k, k+1; `ready`: flag raised when tile (base, base)
+// is final (hoisted-diagonal schedule)
 template <typename T>
-static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, bool first2, const T *V0, const T *V1,
-                       hipStream_t st, int *ready = nullptr) {
+static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, const T *V0, const T *V1, hipStream_t st,
+                       int *ready = nullptr) {
   const int nt = (int)w->nt, m = nt - base;
   if (m <= 0) return BA_OK;
-  ProfScope ps(p, first2 ? PC_LDL_SYRK : PC_LDL_UPDATE, st);
-  if (first2) {
-    const int nblk = m + (m > 1 ? m - 1 : 0);
-    hipLaunchKernelGGL(k_ldl_pair2_rs<T>, dim3(4 * nblk), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, V0, V1, k, base, nt);
-  } else {
-    const int nblk = m * (m + 1) / 2;
-    hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st, w->S, V0, V1, k, base, nt, nblk, ready);
-  }
+  ProfScope ps(p, PC_LDL_UPDATE, st);
+  const int nblk = m * (m + 1) / 2;
+  hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st, w->S,
+                     V0, V1, k, base, nt, nblk, ready);
   return BA_OK;
 }
 
 // Two panels per pass over the trailing matrix:
 //   diag(k) trsm(k) | column update of tile column k+1 | diag(k+1) trsm(k+1) | pair update of everything right of k+1.
-// Look-ahead: the pair update is split into the two tile columns the NEXT panels need (side stream, followed by the next
-// diag/trsm/column/diag/trsm chain) and the rest (main stream), so the latency-bound chain hides behind the bulk GEMM.
-// With per-kernel profiling on, everything runs on one stream so that the event pairs time single kernels.
+//
+// Hoisted diagonal tile (for nt >= HOIST_MIN_TILES + 2; BA_LDL_HOIST=0 disables; never with per-kernel profiling, whose
+// event pairs must time single kernels): the kernel that factors tile (k+2, k+2) is LAUNCHED ahead of time on a second
+// stream -- while CUs are free; once the trailing update fills the GPU a 153 KB-LDS workgroup finds no CU -- and waits in
+// place for the flag the trailing update's first workgroup raises when that tile is final.  It then factors the tile
+// beside the rest of the update: one 59 us diagonal kernel per pair leaves the critical path (37.2 -> 35.4 ms at
+// n = 16002).  Nothing throughput-bound is moved and no CU mask is involved.  (A full look-ahead -- whole panel chain on a
+// priority stream, bulk on a CU-masked stream -- measured 40-51 ms; masking only 1 / 2 / 4 of the 256 CUs off the bulk
+// stream for a hoisted diagonal kernel 42 / 46 / 59 ms: CU-masked streams are slow here, and that code is gone.)
 template <typename T>
 int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b) {
   const int nt = (int)w->nt;
   const int64_t panel = (int64_t)nt * NB * NB;
   T *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
   BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
-  // pairs whose bulk update is shorter than the panel chain gain nothing from giving CUs away: overlap only while
-  // at least OVERLAP_MIN_TILES tile rows remain
-  constexpr int OVERLAP_MIN_TILES = 48;
-  const bool can_overlap = !p->prof_on && w->side_cus > 0 && nt > OVERLAP_MIN_TILES;
-  hipStream_t ss = can_overlap ? w->side : st;  // panel chain
-  hipStream_t sb = can_overlap ? w->bulk : st;  // bulk trailing updates
-  if (can_overlap) {  // fork: both streams start after everything already queued on st (S assembly, memset)
-    BA_HIP_CHECK(hipEventRecord(w->ev_bulk, st));
-    BA_HIP_CHECK(hipStreamWaitEvent(ss, w->ev_bulk, 0));
-    BA_HIP_CHECK(hipStreamWaitEvent(sb, w->ev_bulk, 0));
-  }
-  // Hoisted diagonal tile (default on for nt >= HOIST_MIN_TILES + 2, BA_LDL_HOIST=0 disables): the kernel that factors
-  // tile (k+2, k+2) is LAUNCHED at the top of pair (k, k+1) on a second stream -- while CUs are free; once the trailing
-  // update fills the GPU a 153 KB-LDS workgroup finds no CU -- and waits in place for the flag the trailing update's
-  // first workgroup raises when that tile is final.  It then factors the tile beside the rest of the update: one 59 us
-  // diagonal kernel per pair leaves the critical path.  Nothing throughput-bound is moved, no CU mask is involved (a
-  // CU-masked bulk stream measured 42 / 46 / 59 ms with 1 / 2 / 4 CUs masked off, against 37 ms unmasked).
-  constexpr int HOIST_MIN_TILES = 32;
+  constexpr int HOIST_MIN_TILES = 32;  // below ~2 rounds of tiles the update is shorter than wait + factor
   static const bool hoist_off = [] { const char *e = getenv("BA_LDL_HOIST"); return e && e[0] == '0'; }();
-  w->hoisting = !p->prof_on && !can_overlap && !hoist_off && !w->hoist_disabled && nt >= HOIST_MIN_TILES + 2;
+  w->hoisting = !p->prof_on && !hoist_off && !w->hoist_disabled && nt >= HOIST_MIN_TILES + 2;
   if (w->hoisting) {
     BA_HIP_CHECK(hipMemsetAsync(w->ready, 0, (size_t)nt * sizeof(int), st));
     // one fork for the whole factorisation: the hoisted kernels only depend on their flags (and on stream order among
     // themselves); each gets its CU in the idle gaps of the panel chain before the trailing update it waits for starts
     BA_HIP_CHECK(hipEventRecord(w->ev_top, st));
     BA_HIP_CHECK(hipStreamWaitEvent(w->hoist, w->ev_top, 0));
-    launch_diag(p, w, 0, st);
-    for (int k = 0, q = 0; k < nt; k += 2, q ^= 1) {
-      T *V0 = Vs[q][0], *V1 = Vs[q][1];
-      const bool hoist = (k + 2 < nt) && (nt - k - 2 >= HOIST_MIN_TILES);
-      if (hoist) {  // the next pair's first diagonal kernel: waits in place for ready[k+2]
-        launch_diag(p, w, k + 2, w->hoist, w->ready + k + 2);
-        BA_HIP_CHECK(hipEventRecord(w->ev_chain, w->hoist));
-      }
-      launch_trsm(p, w, k, V0, d_b, st);  // diag(k) is done: prologue, hoisted, or the tail branch below
-      if (k + 1 < nt) {
-        launch_col(p, w, k, V0, st);
-        launch_diag(p, w, k + 1, st);
-        launch_trsm(p, w, k + 1, V1, d_b, st);
-      }
-      if (k + 2 >= nt) break;
-      launch_pair(p, w, k, k + 2, false, V0, V1, st, hoist ? w->ready + k + 2 : nullptr);
-      if (hoist)
-        BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));  // join: Linv / D of tile k+2 are written
-      else
-        launch_diag(p, w, k + 2, st);
-    }
-  } else {
-  bool forked = can_overlap;
-  // prologue chain: panels 0 and 1
-  launch_diag(p, w, 0, ss);
-  launch_trsm(p, w, 0, Vs[0][0], d_b, ss);
-  if (nt > 1) {
-    launch_col(p, w, 0, Vs[0][0], ss);
-    launch_diag(p, w, 1, ss);
-    launch_trsm(p, w, 1, Vs[0][1], d_b, ss);
   }
-  for (int k = 0, q = 0; k + 2 < nt; k += 2, q ^= 1) {
-    T *V0 = Vs[q][0], *V1 = Vs[q][1], *W0 = Vs[q ^ 1][0], *W1 = Vs[q ^ 1][1];
-    if (forked && nt - k - 2 < OVERLAP_MIN_TILES) {  // join: the tail runs on the whole GPU, one stream
-      BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));
-      BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));
-      BA_HIP_CHECK(hipEventRecord(w->ev_bulk, sb));
-      BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_bulk, 0));
-      ss = sb = st;
-      forked = false;
+  launch_diag(p, w, 0, st);
+  for (int k = 0, q = 0; k < nt; k += 2, q ^= 1) {
+    T *V0 = Vs[q][0], *V1 = Vs[q][1];
+    const bool hoist = w->hoisting && (k + 2 < nt) && (nt - k - 2 >= HOIST_MIN_TILES);
+    if (hoist) {  // the next pair's first diagonal kernel: waits in place for ready[k+2]
+      launch_diag(p, w, k + 2, w->hoist, w->ready + k + 2);
+      BA_HIP_CHECK(hipEventRecord(w->ev_chain, w->hoist));
     }
-    if (forked) {
-      BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));  // panels k, k+1 factored
-      BA_HIP_CHECK(hipStreamWaitEvent(sb, w->ev_chain, 0));
-      if (k > 0) BA_HIP_CHECK(hipStreamWaitEvent(ss, w->ev_bulk, 0));  // previous bulk update finished
+    launch_trsm(p, w, k, V0, d_b, st);  // diag(k) is done: first tile, hoisted, or the in-order branch below
+    if (k + 1 < nt) {
+      launch_col(p, w, k, V0, st);
+      launch_diag(p, w, k + 1, st);
+      launch_trsm(p, w, k + 1, V1, d_b, st);
     }
-    if (forked || getenv("BA_LDL_SPLIT_PAIR")) {
-      launch_pair(p, w, k, k + 2, true, V0, V1, ss);   // tile columns k+2, k+3: what the next panels need
-      launch_pair(p, w, k, k + 4, false, V0, V1, sb);  // the rest
-    } else {
-      launch_pair(p, w, k, k + 2, false, V0, V1, st);  // one stream: the whole trailing matrix in one launch
-    }
-    if (forked) BA_HIP_CHECK(hipEventRecord(w->ev_bulk, sb));
-    // next chain: panels k+2, k+3
-    launch_diag(p, w, k + 2, ss);
-    launch_trsm(p, w, k + 2, W0, d_b, ss);
-    if (k + 3 < nt) {
-      launch_col(p, w, k + 2, W0, ss);
-      launch_diag(p, w, k + 3, ss);
-      launch_trsm(p, w, k + 3, W1, d_b, ss);
-    }
+    if (k + 2 >= nt) break;
+    launch_pair(p, w, k, k + 2, V0, V1, st, hoist ? w->ready + k + 2 : nullptr);
+    if (hoist)
+      BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));  // join: Linv / D of tile k+2 are written
+    else
+      launch_diag(p, w, k + 2, st);
   }
-  if (forked) {
-    BA_HIP_CHECK(hipEventRecord(w->ev_chain, ss));
-    BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));
-    BA_HIP_CHECK(hipEventRecord(w->ev_bulk, sb));
-    BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_bulk, 0));
-  }
-  }  // schedules
   BA_HIP_CHECK(hipGetLastError());
   if (zero_pivot) {
     int h = 0;

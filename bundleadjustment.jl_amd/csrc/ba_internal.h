@@ -42,7 +42,7 @@ enum ProfClass {
   PC_SCHUR_RHS,
   PC_LDL_DIAG,
   PC_LDL_TRSM,
-  PC_LDL_SYRK,    // column / two-column updates feeding the next panels (k_ldl_col_rs, k_ldl_pair2_rs)
+  PC_LDL_SYRK,    // update of the next tile column inside a panel pair (k_ldl_col_rs)
   PC_LDL_UPDATE,  // bulk pair update of the trailing matrix (k_ldl_update)
   PC_SOLVE,
   PC_BACKSUB,
@@ -72,9 +72,7 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   bool hoist_disabled = false;   // a hoisted kernel once timed out (kernels serialised by a profiler): never again on this handle
   bool hoisting = false;         // the factorisation forks onto `hoist` (set by dense_ldl_factor's schedule choice)
   bool own_S = true;
-  hipStream_t side = nullptr, bulk = nullptr;      // look-ahead: panel chain / bulk update streams (disjoint CU masks)
-  int side_cus = 0;                                 // 0: no CU-masked streams, factorisation runs on one stream
-  hipEvent_t ev_chain = nullptr, ev_bulk = nullptr;
+  hipEvent_t ev_chain = nullptr;  // recorded behind each hoisted diagonal kernel
 };
 typedef DenseLDLT<double> DenseLDL;
 

@@ -393,7 +393,7 @@ static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 
 // ---- recorded launch sequences ------------------------------------------------------------------------------------------
 static bool graphs_allowed(ba_problem *p, LMWorkFull *w) {
-  if (w->g_off || p->prof_on || p->allreduce || w->ldl.side_cus > 0) return false;  // events / host hook / forked streams
+  if (w->g_off || p->prof_on || p->allreduce) return false;  // per-kernel events / host hook
   // the hoisted-diagonal schedule of large factorisations has a kernel wait for a flag raised by a kernel running
   // beside it: only with real streams is that concurrency certain (and the graphs gain nothing at that size)
   if (w->ldl.nt >= 34) return false;  // = HOIST_MIN_TILES + 2 of dense_ldl_factor
