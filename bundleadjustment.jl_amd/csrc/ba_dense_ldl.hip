@@ -111,10 +111,13 @@ __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__rest
     if (threadIdx.x == 0) {
       int seen = 0;
       const bool abandoned = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2;  // an earlier tile gave up
-      for (unsigned n = 0; n < (1u << 18) && !abandoned; n++) {
-        seen = __hip_atomic_load(wait_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned n = 0; n < (1u << 17) && !abandoned; n++) {
+        // relaxed poll: an acquire at agent scope invalidates this XCD's L2 on every iteration, which the trailing
+        // update running on the same XCD pays for (n = 40000: 421-426 ms against 411 ms without the hoist); the one
+        // acquire that matters is the fence after the loop
+        seen = __hip_atomic_load(wait_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (seen) break;
-        __builtin_amdgcn_s_sleep(64);
+        __builtin_amdgcn_s_sleep(127);
       }
       ok = seen;
       if (!seen) *flag = 2;
@@ -891,8 +894,13 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
   T *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
   BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
   constexpr int HOIST_MIN_TILES = 32;  // below ~2 rounds of tiles the update is shorter than wait + factor
+  // The waiting workgroup keeps one CU of one XCD from the update, whose blocks the hardware deals round-robin to the
+  // XCDs: that XCD runs 32/31 longer and the launch ends with it -- 3 % of the update time, which grows as nt^3 while
+  // the hoisted 59 us per pair grow as nt.  Measured: n = 16002 (nt 126) 37.1 -> 35.6 ms, n = 40000 (nt 313) 411 -> 418 ms;
+  // the model's break-even is nt ~ 250.
+  constexpr int HOIST_MAX_TILES = 224;
   static const bool hoist_off = [] { const char *e = getenv("BA_LDL_HOIST"); return e && e[0] == '0'; }();
-  w->hoisting = !p->prof_on && !hoist_off && !w->hoist_disabled && nt >= HOIST_MIN_TILES + 2;
+  w->hoisting = !p->prof_on && !hoist_off && !w->hoist_disabled && nt >= HOIST_MIN_TILES + 2 && nt <= HOIST_MAX_TILES;
   if (w->hoisting) {
     BA_HIP_CHECK(hipMemsetAsync(w->ready, 0, (size_t)nt * sizeof(int), st));
     // one fork for the whole factorisation: the hoisted kernels only depend on their flags (and on stream order among

@@ -396,7 +396,7 @@ static bool graphs_allowed(ba_problem *p, LMWorkFull *w) {
   if (w->g_off || p->prof_on || p->allreduce) return false;  // per-kernel events / host hook
   // the hoisted-diagonal schedule of large factorisations has a kernel wait for a flag raised by a kernel running
   // beside it: only with real streams is that concurrency certain (and the graphs gain nothing at that size)
-  if (w->ldl.nt >= 34) return false;  // = HOIST_MIN_TILES + 2 of dense_ldl_factor
+  if (w->ldl.nt >= 34) return false;  // = HOIST_MIN_TILES + 2 of dense_ldl_factor (above its HOIST_MAX_TILES graphs gain nothing either)
   const char *e = getenv("BA_LM_GRAPH");
   return !(e && e[0] == '0');
 }
