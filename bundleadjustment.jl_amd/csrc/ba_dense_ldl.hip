@@ -798,7 +798,7 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S) {
     w->own_S = true;
   }
   BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(T)));  // 2 x two panels of L*D
-  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_chain, hipEventDisableTiming));
+  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_chain, hipEventDisableTiming | hipEventReleaseToDevice));
   BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(T)));
   // k_ldl_diag writes the lower triangle of each inverse only; the consumers read whole tiles
   BA_HIP_CHECK(hipMemset(w->Linv, 0, (size_t)nt * NB * NB * sizeof(T)));
@@ -806,7 +806,7 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S) {
   BA_HIP_CHECK(hipMalloc((void **)&w->flag, sizeof(int)));
   BA_HIP_CHECK(hipMalloc((void **)&w->ready, (size_t)nt * sizeof(int)));
   BA_HIP_CHECK(hipStreamCreateWithFlags(&w->hoist, hipStreamNonBlocking));
-  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_top, hipEventDisableTiming));
+  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_top, hipEventDisableTiming | hipEventReleaseToDevice));
   return set_kernel_attrs<T>();
 }
 
