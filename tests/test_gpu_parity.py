@@ -11,6 +11,8 @@ Tolerances (stated, fp64):
     synthetic shapes; 1/2|J delta + r|^2 to 1e-9 relative.
   * LM run: identical accept/reject sequence and iteration count on the small shapes, final objective <= 1e-8 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -429,3 +431,23 @@ def test_lm_step_venice_size_normal_equations(ba, gpu_ok):
     model = 0.5 * float((Jd + r) @ (Jd + r))
     assert abs(half - model) <= 1e-10 * model
     m.close()
+
+
+def test_dense_ldl_hoisted_schedule_and_its_fallback(ba, gpu_ok):
+    """n = 4480 (35 tile rows) is the smallest size that takes the hoisted-diagonal schedule of dense_ldl_factor.  Run it
+    normally, then with every kernel launch serialised by the runtime (AMD_SERIALIZE_KERNEL=3, what a counter-collecting
+    profiler does): the hoisted kernel then waits for a flag nothing can raise, gives up after its bounded polling, and the
+    host must redo the factorisation in order.  Both must solve the system."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import __graft_entry__ as ge; ba = ge.load_package(); "
+            "rng = np.random.default_rng(0); n = 4480; R = rng.standard_normal((n, n)); A = R + R.T; "
+            "A[np.diag_indices(n)] += 4 * np.sqrt(n); b = rng.standard_normal(n); x, ms = ba._lib.dense_ldl_solve(A, b); "
+            "print('REL', np.linalg.norm(A @ x - b) / np.linalg.norm(b))") % root
+    for extra in ({}, {"AMD_SERIALIZE_KERNEL": "3"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rel = float([l for l in r.stdout.splitlines() if l.startswith("REL")][0].split()[1])
+        assert rel < 1e-12, (extra, rel)
