@@ -611,6 +611,11 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const T *
 // DBG (micro-benchmark only, ba_debug_update_bench): bit 0 = store instead of read-modify-write, bit 1 = every
 // workgroup reads the same operand tiles (L2-resident operands), bit 3 = workgroup-shared LDS staging with barriers
 // (the first version: 52.6 TFLOP/s against 59.8 for the wave-private staging that ships).
+// Where the remaining 24 % are NOT: the K loop's MFMA + LDS-read stream alone runs at 78.0 TFLOP/s (k_mfma_probe, modes
+// 0 and 1: the operand reads are free); the two workgroups of a CU having their prologue / epilogue at the same time
+// (delaying every CU's second workgroup by 10 / 20 / 34 us changed nothing: 59.6-59.9); the read-modify-write epilogue
+// and the operands' home (variants 1, 2).  What is left is the staging inside the loop: every wave pulls its own A and B
+// slices, 16 KB per 64 MFMAs, ~9.7 TB/s of L2 -> LDS traffic chip-wide, with a wait for it at every chunk boundary.
 template <typename T, int MODE, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const T *__restrict__ V0,
                                                         const T *__restrict__ V1, int k, int base, int nt,
@@ -1111,5 +1116,87 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
   for (int q = 0; q < 6; q++) cycles6[q] = (double)hs[q];
   *ms_out = ms;
   (void)hipFree(S); (void)hipFree(Li); (void)hipFree(D); (void)hipFree(flag); (void)hipFree(st);
+  return BA_OK;
+}
+
+// ---- MFMA ceiling probe (tools/bench_mfma_probe.py): how close a K loop of the update kernel's shape can get to the
+// f64 matrix peak, without global memory.  MODE 0: MFMAs only, 4x4 accumulator blocks per wave, 2 waves per SIMD;
+// MODE 1: the same with the update kernel's LDS operand reads (8 ds_read_b64 per 16 MFMAs); MODE 2: 4x8 blocks per wave
+// (32 MFMAs per 12 operand reads), one wave per SIMD (launch bound 256 x 1, accumulators spill to AGPRs).
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void k_mfma_probe(double *out, int iters) {
+  typedef double d4p __attribute__((ext_vector_type(4)));
+  constexpr int NC = (MODE == 2) ? 8 : 4;
+  __shared__ double sm[(64 + 128) * 18];
+  for (int i = threadIdx.x; i < (64 + 128) * 18; i += 256) sm[i] = 1.0 + 1e-9 * i;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fk = lane >> 4;
+  d4p acc[4][NC];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < NC; n++) acc[m][n] = (d4p){0, 0, 0, 0};
+  double af[4], bf[NC];
+#pragma unroll
+  for (int m = 0; m < 4; m++) af[m] = 1.0 + lane * 1e-3 + m;
+#pragma unroll
+  for (int n = 0; n < NC; n++) bf[n] = 2.0 - lane * 1e-3 + n;
+  const double *sA = sm, *sB = sm + 64 * 18;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      if (MODE >= 1) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * 18 + kk * 4 + fk];
+#pragma unroll
+        for (int n = 0; n < NC; n++) bf[n] = sB[(((wv & 1) * 64 + 16 * n + fr) & 127) * 18 + kk * 4 + fk];
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < NC; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+  }
+  double s = 0;
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < NC; n++) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int ba_debug_mfma_probe(int mode, int iters, double *tflops_out) {
+  int dev = 0, ncu = 256;
+  BA_HIP_CHECK(hipGetDevice(&dev));
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int per_cu = mode == 2 ? 1 : 2, grid = ncu * per_cu * 4;
+  double *out = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)grid * 256 * sizeof(double)));
+  hipEvent_t e0, e1;
+  BA_HIP_CHECK(hipEventCreate(&e0));
+  BA_HIP_CHECK(hipEventCreate(&e1));
+  auto launch = [&]() {
+    switch (mode) {
+      case 0: hipLaunchKernelGGL(k_mfma_probe<0>, dim3(grid), dim3(256), 0, 0, out, iters); break;
+      case 1: hipLaunchKernelGGL(k_mfma_probe<1>, dim3(grid), dim3(256), 0, 0, out, iters); break;
+      default: hipLaunchKernelGGL(k_mfma_probe<2>, dim3(grid), dim3(256), 0, 0, out, iters);
+    }
+  };
+  launch();
+  BA_HIP_CHECK(hipDeviceSynchronize());
+  BA_HIP_CHECK(hipEventRecord(e0, 0));
+  launch();
+  BA_HIP_CHECK(hipEventRecord(e1, 0));
+  BA_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double nc = mode == 2 ? 8 : 4;
+  const double flops = (double)grid * 4 /*waves*/ * iters * 4 /*kk*/ * 4 * nc * 2048.0;
+  *tflops_out = flops / (ms * 1e-3) / 1e12;
+  (void)hipFree(out);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return BA_OK;
 }
