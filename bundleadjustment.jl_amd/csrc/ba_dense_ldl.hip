@@ -1119,10 +1119,18 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
   return BA_OK;
 }
 
-// ---- MFMA ceiling probe (tools/bench_mfma_probe.py): how close a K loop of the update kernel's shape can get to the
-// f64 matrix peak, without global memory.  MODE 0: MFMAs only, 4x4 accumulator blocks per wave, 2 waves per SIMD;
-// MODE 1: the same with the update kernel's LDS operand reads (8 ds_read_b64 per 16 MFMAs); MODE 2: 4x8 blocks per wave
-// (32 MFMAs per 12 operand reads), one wave per SIMD (launch bound 256 x 1, accumulators spill to AGPRs).
+// ---- MFMA ceiling probes (tools/bench_mfma_probe.py): how close a K loop of the update kernel's shape can get to the
+// f64 matrix peak.  MODE 0: MFMAs only, 4x4 accumulator blocks per wave, 2 waves per SIMD; MODE 1: the same with the
+// update kernel's LDS operand reads (8 ds_read_b64 per 16 MFMAs), no staging; MODE 2: 4x8 blocks per wave, one wave per
+// SIMD, no staging.  Modes 3 / 4 (k_stage_probe): the full wave-private staging loop (global -> registers -> LDS, chunks
+// of 16, next chunk's loads in flight during the MFMAs) on operands in global memory, K = 256 per "tile", 16 tiles per
+// persistent workgroup, no C tile traffic: 3 = the shipped geometry (64x64 per wave, 2 workgroups per CU), 4 = 64x128
+// per wave, 1 workgroup per CU.
+// Measured (TFLOP/s): 0: 78.0   1: 78.0   2: 58.6 (compiler spills)   3: 67.7-69.8   4: 64.3-65.1.
+// With them: the shipped kernel's 59.8 in tools/bench_update.py becomes 64-65 with a store-only epilogue (variant 1), and
+// reading the C tile costs the same 6-7 TFLOP/s wherever the loads are placed (end of tile, or start of tile into the
+// accumulators, with or without persistent workgroups): the pair update moves 2 x 0.98 GB of C per launch for 0.063
+// TFLOP, i.e. at K = 256 the trailing matrix's HBM traffic is a third of the kernel's time when it is not overlapped.
 namespace {
 template <int MODE>
 __global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void k_mfma_probe(double *out, int iters) {
@@ -1165,37 +1173,138 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void k_mfma_probe(double 
     for (int n = 0; n < NC; n++) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
+
+// staging probe: NCB = column blocks of 16 per wave (4: 64x64 wave tile, 8: 64x128)
+template <int NCB>
+__global__ __launch_bounds__(256, (NCB == 8 ? 1 : 2)) void k_stage_probe(const double *__restrict__ Aop,
+                                                                          const double *__restrict__ Bop, double *out,
+                                                                          int tiles_per_wg, int ntile_rows) {
+  typedef double d4p __attribute__((ext_vector_type(4)));
+  typedef double d2p __attribute__((ext_vector_type(2)));
+  constexpr int BR = 16 * NCB;  // B rows per wave
+  constexpr int LD = 18;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  double *lds = reinterpret_cast<double *>(smraw);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fk = lane >> 4;
+  double *sA = lds + wv * ((64 + BR) * LD), *sB = sA + 64 * LD;
+  const int lrow = lane >> 3, lc2 = lane & 7;  // 8 lanes cover the 16 doubles of a chunk row
+  constexpr int NLA = 64 / 8, NLB = BR / 8;
+  d4p acc[4][NCB];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < NCB; n++) acc[m][n] = (d4p){0, 0, 0, 0};
+  for (int t = 0; t < tiles_per_wg; t++) {
+    // operand tiles of this step: row-major tiles of 128 x 128 doubles; every workgroup walks its own sequence
+    const int ti = (blockIdx.x * 7 + t * 3) % ntile_rows, tj = (blockIdx.x * 5 + t) % ntile_rows;
+    const double *Ab = Aop + (size_t)ti * NB * NB + (size_t)((wv >> 1) * 64) * NB;
+    const double *Bb = Bop + (size_t)tj * NB * NB + (size_t)(((wv & 1) * BR) % NB) * NB;
+    d2p pa[NLA], pb[NLB];
+#pragma unroll
+    for (int q = 0; q < NLA; q++) pa[q] = *reinterpret_cast<const d2p *>(Ab + (lrow + 8 * q) * NB + 2 * lc2);
+#pragma unroll
+    for (int q = 0; q < NLB; q++) pb[q] = *reinterpret_cast<const d2p *>(Bb + ((lrow + 8 * q) % NB) * NB + 2 * lc2);
+    for (int ch = 0; ch < 16; ch++) {  // K = 256 in chunks of 16
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < NLA; q++) *reinterpret_cast<d2p *>(sA + (lrow + 8 * q) * LD + 2 * lc2) = pa[q];
+#pragma unroll
+      for (int q = 0; q < NLB; q++) *reinterpret_cast<d2p *>(sB + (lrow + 8 * q) * LD + 2 * lc2) = pb[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (ch + 1 < 16) {
+        const int k0 = ((ch + 1) & 7) * 16;
+#pragma unroll
+        for (int q = 0; q < NLA; q++) pa[q] = *reinterpret_cast<const d2p *>(Ab + (lrow + 8 * q) * NB + k0 + 2 * lc2);
+#pragma unroll
+        for (int q = 0; q < NLB; q++) pb[q] = *reinterpret_cast<const d2p *>(Bb + ((lrow + 8 * q) % NB) * NB + k0 + 2 * lc2);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        double af[4], bf[NCB];
+#pragma unroll
+        for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * LD + kk * 4 + fk];
+#pragma unroll
+        for (int n = 0; n < NCB; n++) bf[n] = sB[(16 * n + fr) * LD + kk * 4 + fk];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int n = 0; n < NCB; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  double s = 0;  // consume the accumulators one column block at a time (no 256-register reduction)
+#pragma unroll
+  for (int n = 0; n < NCB; n++) {
+    double sn = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) sn += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    s += sn;
+  }
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
 }  // namespace
 
 extern "C" int ba_debug_mfma_probe(int mode, int iters, double *tflops_out) {
   int dev = 0, ncu = 256;
   BA_HIP_CHECK(hipGetDevice(&dev));
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const int per_cu = mode == 2 ? 1 : 2, grid = ncu * per_cu * 4;
-  double *out = nullptr;
-  BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)grid * 256 * sizeof(double)));
   hipEvent_t e0, e1;
   BA_HIP_CHECK(hipEventCreate(&e0));
   BA_HIP_CHECK(hipEventCreate(&e1));
-  auto launch = [&]() {
-    switch (mode) {
-      case 0: hipLaunchKernelGGL(k_mfma_probe<0>, dim3(grid), dim3(256), 0, 0, out, iters); break;
-      case 1: hipLaunchKernelGGL(k_mfma_probe<1>, dim3(grid), dim3(256), 0, 0, out, iters); break;
-      default: hipLaunchKernelGGL(k_mfma_probe<2>, dim3(grid), dim3(256), 0, 0, out, iters);
-    }
-  };
-  launch();
-  BA_HIP_CHECK(hipDeviceSynchronize());
-  BA_HIP_CHECK(hipEventRecord(e0, 0));
-  launch();
-  BA_HIP_CHECK(hipEventRecord(e1, 0));
-  BA_HIP_CHECK(hipEventSynchronize(e1));
+  double *out = nullptr, *Aop = nullptr, *Bop = nullptr;
   float ms = 0;
-  BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  const double nc = mode == 2 ? 8 : 4;
-  const double flops = (double)grid * 4 /*waves*/ * iters * 4 /*kk*/ * 4 * nc * 2048.0;
+  double flops = 0;
+  if (mode <= 2) {
+    const int per_cu = mode == 2 ? 1 : 2, grid = ncu * per_cu * 4;
+    BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)grid * 256 * sizeof(double)));
+    auto launch = [&]() {
+      switch (mode) {
+        case 0: hipLaunchKernelGGL(k_mfma_probe<0>, dim3(grid), dim3(256), 0, 0, out, iters); break;
+        case 1: hipLaunchKernelGGL(k_mfma_probe<1>, dim3(grid), dim3(256), 0, 0, out, iters); break;
+        default: hipLaunchKernelGGL(k_mfma_probe<2>, dim3(grid), dim3(256), 0, 0, out, iters);
+      }
+    };
+    launch();
+    BA_HIP_CHECK(hipDeviceSynchronize());
+    BA_HIP_CHECK(hipEventRecord(e0, 0));
+    launch();
+    BA_HIP_CHECK(hipEventRecord(e1, 0));
+    BA_HIP_CHECK(hipEventSynchronize(e1));
+    BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double nc = mode == 2 ? 8 : 4;
+    flops = (double)grid * 4 /*waves*/ * iters * 4 /*kk*/ * 4 * nc * 2048.0;
+  } else {
+    const int ncb = mode == 3 ? 4 : 8, per_cu = mode == 3 ? 2 : 1, grid = ncu * per_cu, tiles = iters > 0 ? iters : 16;
+    const int ntile_rows = 120;  // 2 x 15.7 MB of operands: cache-resident like the panels of a pair update
+    const size_t lds_bytes = (size_t)4 * (64 + 16 * ncb) * 18 * sizeof(double);
+    BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)grid * 256 * sizeof(double)));
+    BA_HIP_CHECK(hipMalloc((void **)&Aop, (size_t)ntile_rows * NB * NB * sizeof(double)));
+    BA_HIP_CHECK(hipMalloc((void **)&Bop, (size_t)ntile_rows * NB * NB * sizeof(double)));
+    BA_HIP_CHECK(hipMemset(Aop, 0, (size_t)ntile_rows * NB * NB * sizeof(double)));
+    BA_HIP_CHECK(hipMemset(Bop, 0, (size_t)ntile_rows * NB * NB * sizeof(double)));
+    if (mode == 3)
+      BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_probe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    else
+      BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_probe<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    auto launch = [&]() {
+      if (mode == 3) hipLaunchKernelGGL(k_stage_probe<4>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
+      else hipLaunchKernelGGL(k_stage_probe<8>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
+    };
+    launch();
+    BA_HIP_CHECK(hipDeviceSynchronize());
+    BA_HIP_CHECK(hipEventRecord(e0, 0));
+    launch();
+    BA_HIP_CHECK(hipEventRecord(e1, 0));
+    BA_HIP_CHECK(hipEventSynchronize(e1));
+    BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    flops = (double)grid * 4 * tiles * 16 /*chunks*/ * 4 /*kk*/ * 4 * ncb * 2048.0;
+  }
   *tflops_out = flops / (ms * 1e-3) / 1e12;
-  (void)hipFree(out);
+  if (out) (void)hipFree(out);
+  if (Aop) (void)hipFree(Aop);
+  if (Bop) (void)hipFree(Bop);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return BA_OK;
