@@ -51,6 +51,31 @@ def test_reader_roundtrip(ba, small_prob, tmp_path, ext, T):
     assert np.array_equal(pt2d, p["pt2d"].astype(T)) and np.array_equal(x0, p["x0"].astype(T))
 
 
+def test_reader_binary_cache(ba, small_prob, tmp_path, monkeypatch):
+    """The parsed arrays are cached beside the file and reused until the file changes; BA_READ_CACHE=0 disables."""
+    import time
+    p = small_prob
+    path = str(tmp_path / "Synth" / "problem-12-400-pre.txt.bz2")
+    ba.synthetic.write_bal(path, p)
+    a = ba.readfile(path)
+    cache = path + ".f64.balcache.npz"
+    assert os.path.exists(cache)
+    b = ba.readfile(path)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    # a stale cache (source rewritten with different content) is ignored
+    q = dict(p)
+    q["pt2d"] = p["pt2d"] + 1.0
+    time.sleep(0.05)
+    ba.synthetic.write_bal(path, q)
+    os.utime(path, (time.time() + 5, time.time() + 5))
+    c = ba.readfile(path)
+    assert np.allclose(c[2], q["pt2d"]) and not np.allclose(c[2], a[2])
+    monkeypatch.setenv("BA_READ_CACHE", "0")
+    os.remove(cache) if os.path.exists(cache) else None
+    ba.readfile(path)
+    assert not os.path.exists(cache)
+
+
 def test_reader_camera_order(ba, tmp_path):
     # file order r t f k1 k2 -> stored r t k1 k2 f (src/ReadFiles.jl:32-43)
     path = str(tmp_path / "one.txt")
