@@ -118,14 +118,15 @@ int build_tasks(ba_problem *p, SchurTasks *T) {
   return BA_OK;
 }
 
+// [S tiles | rhs(npad) | gc(npad) | hdiag(npad) | SH_COUNT scalars]: gc, hdiag and the first scalars are one all-reduce
 int64_t reduce_layout(ba_problem *p, int64_t *off_rhs, int64_t *off_gc, int64_t *off_scal) {
   const int64_t n = 9 * p->ncams;
   const int64_t tiles = dense_ldl_tiles_doubles(n);
   const int64_t npad = ((n + NB - 1) / NB > 0 ? (n + NB - 1) / NB : 1) * NB;
   if (off_rhs) *off_rhs = tiles;
   if (off_gc) *off_gc = tiles + npad;
-  if (off_scal) *off_scal = tiles + 2 * npad;
-  return tiles + 2 * npad + SH_COUNT;
+  if (off_scal) *off_scal = tiles + 3 * npad;
+  return tiles + 3 * npad + SH_COUNT;
 }
 
 struct LMState {
@@ -215,6 +216,7 @@ static int lm_ensure(ba_problem *p) {
   w->npad = w->ldl.n;
   w->rhs = w->s.red + w->s.off_rhs;
   w->gc = w->s.red + w->s.off_gc;
+  w->hdiag = w->gc + w->npad;
   w->scal = w->s.red + w->s.off_scal;
   BA_HIP_CHECK(hipMemset(w->s.red + w->s.off_rhs, 0, (size_t)(w->s.red_doubles - w->s.off_rhs) * sizeof(double)));
   BA_CHECK(dmalloc(&w->x, w->nvar));
@@ -304,8 +306,10 @@ static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too
   BA_CHECK(launch_cam_blocks(p, w->J, w->r, w->Hcc, w->gc, st));
   BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->gp, w->partial, w->scal, SH_GP, st));
   BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->x, w->partial, w->scal, SH_X_P, st));
-  // gc and the linearisation scalars are adjacent in the reduce buffer: one all-reduce
-  BA_CHECK(comm_sum(p, w, w->s.off_gc, w->npad + SH_LIN_COUNT, st));
+  // gc, the diagonal of the camera block (the column scalings need the global one) and the linearisation scalars are
+  // adjacent in the reduce buffer: one all-reduce
+  BA_CHECK(launch_hcc_diag(p, w->Hcc, w->hdiag, st));
+  BA_CHECK(comm_sum(p, w, w->s.off_gc, 2 * w->npad + SH_LIN_COUNT, st));
   BA_CHECK(launch_sumsq(p, w->n, w->gc, w->partial, w->s.scal_rep, RP_GC, st));
   BA_CHECK(launch_sumsq(p, w->n, w->x + 3 * p->npnts, w->partial, w->s.scal_rep, RP_X_C, st));
   return BA_OK;
@@ -330,9 +334,8 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
   BA_CHECK(launch_schur_rhs(p, w->J, w->r, w->u, w->rhs, st));
   BA_CHECK(comm_sum(p, w, 0, w->s.off_gc, st));  // S tiles and rhs are adjacent
-  if (normalize != 0) {  // :J / :A column scaling of the camera system (Hcc must be the global sum: multi-GPU runs
-                         // reduce it with gc, see refresh_linearisation)
-    BA_CHECK(launch_cam_scale(p, w->Hcc, normalize == 2 ? lambda : 0.0, w->colscale, st, d_lambda));
+  if (normalize != 0) {  // :J / :A column scaling of the camera system from the GLOBAL diagonal (refresh_linearisation)
+    BA_CHECK(launch_cam_scale(p, w->hdiag, normalize == 2 ? lambda : 0.0, w->colscale, st, d_lambda));
     BA_CHECK(launch_scale_S(p, w->n, w->ldl.nt, w->colscale, w->ldl.S, st));
     BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));
   }
@@ -576,10 +579,6 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   }
   if (o->x_f32 && p->world > 1) {
     ba_set_error("ba_lm_solve: eltype(x) = Float32 runs are single-GPU only for now");
-    return BA_ERR_ARG;
-  }
-  if (o->normalize != 0 && p->world > 1) {
-    ba_set_error("ba_lm_solve: normalize != :None is single-GPU only for now (Hcc is not all-reduced)");
     return BA_ERR_ARG;
   }
   BA_HIP_CHECK(hipSetDevice(p->device));

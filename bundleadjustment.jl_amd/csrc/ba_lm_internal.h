@@ -23,6 +23,7 @@ struct LMWork {
   double *Hpp = nullptr, *gp = nullptr, *Uinv = nullptr, *u = nullptr;
   double *Yobs = nullptr;                // 6/obs: U^-1 A_b' of the current damping
   double *Hcc = nullptr, *gc = nullptr;  // gc: 9*ncams
+  double *hdiag = nullptr;               // npad: diag of the camera block of J'J summed over all ranks (column scalings)
   double *rhs = nullptr;                 // npad
   double *colscale = nullptr;            // nvar (normalize != None)
   double *partial = nullptr;             // RED_BLOCKS
@@ -47,7 +48,8 @@ int launch_model_sq(ba_problem *p, const double *d_J, const double *d_r, const d
 int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial, double *d_scal, int slot,
                  hipStream_t st);
 int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st);
-int launch_cam_scale(ba_problem *p, const double *d_Hcc, double add, double *d_dsc, hipStream_t st,
+int launch_hcc_diag(ba_problem *p, const double *d_Hcc, double *d_hdiag, hipStream_t st);
+int launch_cam_scale(ba_problem *p, const double *d_hdiag, double add, double *d_dsc, hipStream_t st,
                      const double *d_lambda = nullptr);
 int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, double *d_S, hipStream_t st);
 int launch_scale_scalar(ba_problem *p, int64_t n, double *d_v, double alpha, hipStream_t st);

@@ -265,15 +265,24 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
 // scales the columns of J by their 2-norms (:J) or those of [J; sqrt(lambda) I] (:A) before factorising.  The point
 // columns are eliminated in closed 3x3 form here, so only the camera columns matter: d_j = sqrt(diag(Hcc)_j [+ lambda]),
 // S <- D^-1 S D^-1, rhs <- D^-1 rhs, and afterwards dc <- D^-1 dc'.  Same step in exact arithmetic, better conditioned.
-__global__ __launch_bounds__(BLK) void k_cam_scale(int64_t ncams, const double *__restrict__ Hcc, double add,
+// hdiag: diag(J'J) of the camera columns, summed over ALL ranks (k_hcc_diag + the gc all-reduce): the column norms are
+// those of the whole Jacobian, not of a rank's shard.
+__global__ __launch_bounds__(BLK) void k_cam_scale(int64_t ncams, const double *__restrict__ hdiag, double add,
                                                     const double *__restrict__ lam_dev, double *__restrict__ dsc) {
   int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
   if (i >= 9 * ncams) return;
   if (lam_dev) add *= lam_dev[0];
+  double v = sqrt(hdiag[i] + add);
+  dsc[i] = (v != 0.0) ? v : 1.0;  // col_norms[j] == 0 columns are left alone (lma_aux.jl:120,148)
+}
+
+// this rank's diag(Hcc) (packed lower 9x9 per camera) -> the 9*ncams vector that is all-reduced with gc
+__global__ __launch_bounds__(BLK) void k_hcc_diag(int64_t ncams, const double *__restrict__ Hcc, double *__restrict__ hdiag) {
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i >= 9 * ncams) return;
   int64_t c = i / 9;
   int j = (int)(i - 9 * c);
-  double v = sqrt(Hcc[45 * c + j * (j + 1) / 2 + j] + add);
-  dsc[i] = (v != 0.0) ? v : 1.0;  // col_norms[j] == 0 columns are left alone (lma_aux.jl:120,148)
+  hdiag[i] = Hcc[45 * c + j * (j + 1) / 2 + j];
 }
 
 // one workgroup per stored tile: S_ij /= d_i d_j   (padding rows/columns have d = 1)
@@ -453,10 +462,17 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
   return BA_OK;
 }
 
-int launch_cam_scale(ba_problem *p, const double *d_Hcc, double add, double *d_dsc, hipStream_t st,
+int launch_hcc_diag(ba_problem *p, const double *d_Hcc, double *d_hdiag, hipStream_t st) {
+  if (p->ncams == 0) return BA_OK;
+  hipLaunchKernelGGL(k_hcc_diag, dim3(grid_for(9 * p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_Hcc, d_hdiag);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_cam_scale(ba_problem *p, const double *d_hdiag, double add, double *d_dsc, hipStream_t st,
                      const double *d_lambda) {
   if (p->ncams == 0) return BA_OK;
-  hipLaunchKernelGGL(k_cam_scale, dim3(grid_for(9 * p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_Hcc, add, d_lambda,
+  hipLaunchKernelGGL(k_cam_scale, dim3(grid_for(9 * p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_hdiag, add, d_lambda,
                      d_dsc);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;

@@ -20,12 +20,17 @@ def main():
     st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(nlp), "LDL", "AMD", "None", False)
     x = ba.parallel.gather_solution(st.solution, info, prob["ncams"])
     out = dict(rank=rank, iter=st.iter, objective=st.objective, status=st.status, calls=red.calls)
+    # column scaling needs the GLOBAL column norms of J: diag(Hcc) is all-reduced with gc
+    stj = ba.Levenberg_Marquardt(ba.FeasibilityResidual(nlp), "LDL", "AMD", "J", False)
+    out.update(iter_j=stj.iter, objective_j=stj.objective, status_j=stj.status)
     if rank == 0:
         full = ba.BALNLPModel(arrays=arrays, device=0)
         ref = ba.Levenberg_Marquardt(ba.FeasibilityResidual(full), "LDL", "AMD", "None", False)
         out.update(ref_iter=ref.iter, ref_objective=ref.objective, ref_status=ref.status,
                    dx=float(np.linalg.norm(x - ref.solution) / np.linalg.norm(ref.solution)),
                    log_equal=[r[7] for r in st.log] == [r[7] for r in ref.log])
+        refj = ba.Levenberg_Marquardt(ba.FeasibilityResidual(full), "LDL", "AMD", "J", False)
+        out.update(ref_iter_j=refj.iter, ref_objective_j=refj.objective, ref_status_j=refj.status)
         json.dump(out, open(sys.argv[1], "w"))
         full.close()
     nlp.close()

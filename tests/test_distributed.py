@@ -47,6 +47,9 @@ def test_sharded_lm_two_ranks_one_gpu(tmp_path, gpu_ok):
     assert abs(res["objective"] - res["ref_objective"]) <= 1e-9 * res["ref_objective"]
     assert res["dx"] <= 1e-7
     assert res["calls"] >= 2 * res["iter"]
+    # normalize = :J on two ranks: same run as on one (the scaling uses the all-reduced diagonal of J'J)
+    assert res["iter_j"] == res["ref_iter_j"] and res["status_j"] == res["ref_status_j"]
+    assert abs(res["objective_j"] - res["ref_objective_j"]) <= 1e-9 * res["ref_objective_j"]
 
 
 @pytest.mark.gpu
