@@ -577,10 +577,6 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     ba_set_error("ba_lm_solve: normalize must be 0 (:None), 1 (:J) or 2 (:A)");
     return BA_ERR_ARG;
   }
-  if (o->x_f32 && p->world > 1) {
-    ba_set_error("ba_lm_solve: eltype(x) = Float32 runs are single-GPU only for now");
-    return BA_ERR_ARG;
-  }
   BA_HIP_CHECK(hipSetDevice(p->device));
   const double t_start = wall();
   BA_CHECK(lm_ensure(p));

@@ -23,6 +23,15 @@ def main():
     # column scaling needs the GLOBAL column norms of J: diag(Hcc) is all-reduced with gc
     stj = ba.Levenberg_Marquardt(ba.FeasibilityResidual(nlp), "LDL", "AMD", "J", False)
     out.update(iter_j=stj.iter, objective_j=stj.objective, status_j=stj.status)
+    # a Float32 model (eltype(x) = Float32) on two ranks; tolerances of the reference's Float32 experiment
+    tol32 = dict(oatol=1e-4, ortol=1e-4, atol=1e-4, rtol=1e-5, satol=1e-6, srtol=1e-7)
+    l32 = list(local)
+    l32[2], l32[3] = l32[2].astype(np.float32), l32[3].astype(np.float32)
+    nlp32 = ba.BALNLPModel(arrays=tuple(l32), T=np.float32, device=0)
+    red32 = ba.parallel.CameraBlockReducer(nlp32)
+    st32 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(nlp32), "LDL", "AMD", "None", False, **tol32)
+    out.update(objective_32=st32.objective, status_32=st32.status)
+    nlp32.close()
     if rank == 0:
         full = ba.BALNLPModel(arrays=arrays, device=0)
         ref = ba.Levenberg_Marquardt(ba.FeasibilityResidual(full), "LDL", "AMD", "None", False)
@@ -31,6 +40,12 @@ def main():
                    log_equal=[r[7] for r in st.log] == [r[7] for r in ref.log])
         refj = ba.Levenberg_Marquardt(ba.FeasibilityResidual(full), "LDL", "AMD", "J", False)
         out.update(ref_iter_j=refj.iter, ref_objective_j=refj.objective, ref_status_j=refj.status)
+        a32 = list(arrays)
+        a32[2], a32[3] = a32[2].astype(np.float32), a32[3].astype(np.float32)
+        full32 = ba.BALNLPModel(arrays=tuple(a32), T=np.float32, device=0)
+        ref32 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(full32), "LDL", "AMD", "None", False, **tol32)
+        out.update(ref_objective_32=ref32.objective, ref_status_32=ref32.status)
+        full32.close()
         json.dump(out, open(sys.argv[1], "w"))
         full.close()
     nlp.close()

@@ -50,6 +50,8 @@ def test_sharded_lm_two_ranks_one_gpu(tmp_path, gpu_ok):
     # normalize = :J on two ranks: same run as on one (the scaling uses the all-reduced diagonal of J'J)
     assert res["iter_j"] == res["ref_iter_j"] and res["status_j"] == res["ref_status_j"]
     assert abs(res["objective_j"] - res["ref_objective_j"]) <= 1e-9 * res["ref_objective_j"]
+    # Float32 iterates: sharding changes the order of the camera-side sums, Float32 rounding of x can amplify that
+    assert abs(res["objective_32"] - res["ref_objective_32"]) <= 1e-3 * res["ref_objective_32"]
 
 
 @pytest.mark.gpu
