@@ -1127,6 +1127,8 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
 // persistent workgroup, no C tile traffic: 3 = the shipped geometry (64x64 per wave, 2 workgroups per CU), 4 = 64x128
 // per wave, 1 workgroup per CU.
 // Measured (TFLOP/s): 0: 78.0   1: 78.0   2: 58.6 (compiler spills)   3: 67.7-69.8   4: 64.3-65.1.
+// (Also tried in this probe: two LDS buffers of 8-wide chunks per wave at the same 73.7 KB, row stride 9 doubles: 43 --
+// the 72-byte rows break the 16-byte LDS writes.)
 // With them: the shipped kernel's 59.8 in tools/bench_update.py becomes 64-65 with a store-only epilogue (variant 1), and
 // reading the C tile costs the same 6-7 TFLOP/s wherever the loads are placed (end of tile, or start of tile into the
 // accumulators, with or without persistent workgroups): the pair update moves 2 x 0.98 GB of C per launch for 0.063
