@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only; invalid as a result)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-full", default="dubrovnik-356",
+                    help="workload of the fully timed CPU iteration reported as cpu_baseline_full beside the GPU's time on the "
+                         "same shape (N = 1 only; 'none' skips it)")
     ap.add_argument("--facto-type", choices=["f64", "f32"], default="f64",
                     help="facto_type of lm.jl (f32 = the diffprecsions.jl path, BASELINE config 5); the default line is f64")
     ap.add_argument("--backend", default=os.environ.get("BA_BENCH_BACKEND", "nccl"),
@@ -72,9 +75,26 @@ def lm_fixed_iterations(ba, fr, k, x=None):
                                   oatol=0.0, ortol=0.0, atol=0.0, rtol=0.0, log=False, facto_type=FACTO_TYPE)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N rank processes (torch.distributed.run, one per
+    GPU, rendezvous on 127.0.0.1) from THIS process, which has not touched the GPU, and leave with their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     global FACTO_TYPE
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     if args.facto_type == "f32":
         import numpy as _np
         FACTO_TYPE = _np.float32
@@ -83,9 +103,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] launched with WORLD_SIZE={world} but --gpus {args.gpus}: running {world} rank(s)", file=sys.stderr)
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -222,6 +241,41 @@ def main():
                    jacobian_mnnz_per_s=24.0 * nobs_g / (s.t_jac / max(1, s.n_jac)) / 1e6,
                    t_factor_s=t_fact, factor_fraction_timed=frac, lnz=int(s.lnz), wall_s=time.time() - t0)
 
+    # ---- one FULLY timed CPU iteration (no cap, no extrapolation) on a shape the oracle finishes, beside the GPU's time
+    # on that same shape from this same process ------------------------------------------------------------------------
+    cpu_full = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.cpu_full != "none":
+        orc = ge.load_oracle()
+        prob2 = ba.synthetic.make_named(args.cpu_full)
+        nlp2 = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob2), device=local_rank, model_name=args.cpu_full)
+        fr2 = ba.FeasibilityResidual(nlp2)
+        lm_fixed_iterations(ba, fr2, 3)
+        torch.cuda.synchronize()
+        k2 = 20
+        tg = time.perf_counter()
+        st2 = lm_fixed_iterations(ba, fr2, k2)
+        torch.cuda.synchronize()
+        gpu_ms = 1e3 * (time.perf_counter() - tg) / k2
+        nlp2.close()
+        t0 = time.time()
+        rc, _, s2, _ = orc.lm_solve(prob2["ncams"], prob2["npnts"], prob2["cam_idx1"], prob2["pnt_idx1"], prob2["pt2d"],
+                                    prob2["x0"], variant=1, max_iter_timed=1)
+        # one accepted iteration of lm.jl: factor + solve + trial residual + Jacobian + sparse() + J'r, every phase timed whole
+        t_iter = (s2.t_facto / max(1, s2.n_facto) + s2.t_solve / max(1, s2.n_facto) + s2.t_residual / max(1, s2.n_res)
+                  + s2.t_jac / max(1, s2.n_jac) + s2.t_jtr / max(1, s2.n_jac) + s2.t_assemble / max(1, s2.n_sparse))
+        cores2 = orc.lib().orc_num_threads()
+        cpu_full = dict(value=1.0 / t_iter, unit="LM iterations/s", cores=cores2, kind="port", workload=args.cpu_full,
+                        sample=(f"1 complete LM iteration of oracle/ba_oracle.c on the {args.cpu_full} shape (ncams={prob2['ncams']} "
+                                f"npnts={prob2['npnts']} nobs={prob2['nobs']}): numeric LDL' {s2.t_facto:.2f}s on 1 thread, timed to "
+                                f"the end; solve {s2.t_solve:.2f}s; residual on {cores2} threads, Jacobian on {min(3, cores2)}; "
+                                f"symbolic analysis {s2.t_analyse:.1f}s (one-off) excluded"),
+                        s_per_iteration=t_iter, t_factor_s=s2.t_facto / max(1, s2.n_facto), factor_fraction_timed=1.0,
+                        lnz=int(s2.lnz), wall_s=time.time() - t0, rc=rc,
+                        gpu_ms_per_step_same_shape=gpu_ms, gpu_it_per_s_same_shape=1e3 / gpu_ms,
+                        gpu_over_cpu=(1e3 / gpu_ms) * t_iter,
+                        reference_log=("benchmark/first/lm_big.log:158-221 (real Dubrovnik-356 file, unknown CPU): 65 s per "
+                                       "iteration" if args.cpu_full == "dubrovnik-356" else None))
+
     if rank == 0:
         out = {
             "metric": f"LM iterations/sec on BAL {args.workload} (synthetic BAL-shaped), plus Jacobian Mnnz/sec",
@@ -247,6 +301,7 @@ def main():
             "roofline": roof,
             "roofline_jacobian": roof_jac,
             "cpu_baseline": cpu,
+            "cpu_baseline_full": cpu_full,
             "kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1] > 0},
             "setup_s": t_setup,
         }

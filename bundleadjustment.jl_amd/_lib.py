@@ -52,7 +52,7 @@ SYMBOLS = [
     "ba_jac_structure", "ba_jac_coord", "ba_jac_coord_f32", "ba_jtr", "ba_residual_dev", "ba_residual_f32_dev",
     "ba_jac_structure_dev", "ba_jac_coord_dev", "ba_jac_coord_f32_dev", "ba_jtr_dev", "ba_dev_malloc", "ba_dev_free",
     "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_synchronize", "ba_lm_solve", "ba_lm_reduce_doubles", "ba_lm_set_comm",
-    "ba_lm_step", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
+    "ba_lm_step", "ba_lm_step_f32", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
 ]
 
 _lib = None
@@ -93,6 +93,7 @@ def lib():
     L.ba_lm_reduce_doubles.argtypes = [vp, C.POINTER(i64)]
     L.ba_lm_set_comm.argtypes = [vp, C.c_int, C.c_int, vp, i64, ALLREDUCE_CB, vp]
     L.ba_lm_step.argtypes = [vp, vp, f64, vp, C.POINTER(f64), vp]
+    L.ba_lm_step_f32.argtypes = [vp, vp, f64, vp, C.POINTER(f64), vp]
     L.ba_profile_enable.argtypes = [vp, C.c_int]
     L.ba_profile_reset.argtypes = [vp]
     L.ba_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(f64), C.POINTER(i64), C.POINTER(C.c_int)]

@@ -358,8 +358,9 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   return BA_OK;
 }
 
-static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st) {
-  BA_CHECK(launch_model_sq(p, w->J, w->r, w->delta, w->partial, w->scal, SH_MODEL, st));
+// cr: the model value is |J delta + cr r|^2 (1 outside the line search)
+static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st, double cr = 1.0) {
+  BA_CHECK(launch_model_sq(p, w->J, w->r, w->delta, w->partial, w->scal, SH_MODEL, st, cr));
   BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->delta, w->partial, w->scal, SH_DELTA_P, st));
   BA_CHECK(launch_sumsq(p, w->n, w->delta + 3 * p->npnts, w->partial, w->s.scal_rep, RP_DELTA_C, st));
   return BA_OK;
@@ -531,8 +532,8 @@ extern "C" int ba_lm_set_comm(ba_problem *p, int rank, int world, double *d_redu
   return BA_OK;
 }
 
-extern "C" int ba_lm_step(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
-                          double *jtr) {
+static int lm_step_impl(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
+                        double *jtr, bool facto_f32) {
   if (!p || !x || !delta) {
     ba_set_error("ba_lm_step: null argument");
     return BA_ERR_ARG;
@@ -543,11 +544,11 @@ extern "C" int ba_lm_step(ba_problem *p, const double *x, double lambda, double 
   hipStream_t st = p->stream;
   BA_HIP_CHECK(hipMemcpyAsync(w->x, x, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
   BA_CHECK(refresh_linearisation(p, w, true, st));
-  BA_CHECK(linear_step(p, w, lambda, 0, st));
+  BA_CHECK(linear_step(p, w, lambda, 0, st, facto_f32));
   {  // same fallback as the LM loop: a hoisted diagonal kernel that gave up -> in-order schedule, redo the step
-    BA_HIP_CHECK(hipMemcpyAsync(w->h_flag, w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    BA_HIP_CHECK(hipMemcpyAsync(w->h_flag, facto_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
     BA_HIP_CHECK(hipStreamSynchronize(st));
-    if (hoist_gave_up(w)) BA_CHECK(linear_step(p, w, lambda, 0, st));
+    if (hoist_gave_up(w)) BA_CHECK(linear_step(p, w, lambda, 0, st, facto_f32));
   }
   BA_CHECK(check_pivot(p, w, st));
   BA_CHECK(step_scalars(p, w, st));
@@ -563,6 +564,16 @@ extern "C" int ba_lm_step(ba_problem *p, const double *x, double lambda, double 
   return BA_OK;
 }
 
+extern "C" int ba_lm_step(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
+                          double *jtr) {
+  return lm_step_impl(p, x, lambda, delta, half_sq_model, jtr, false);
+}
+
+extern "C" int ba_lm_step_f32(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
+                              double *jtr) {
+  return lm_step_impl(p, x, lambda, delta, half_sq_model, jtr, true);
+}
+
 extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, ba_lm_stats *stats, ba_log_cb cb,
                            void *cb_ctx) {
   if (!p || !o || !x_inout || !stats) {
@@ -571,6 +582,10 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   }
   if (o->variant != 0 && o->variant != 1) {
     ba_set_error("ba_lm_solve: variant must be 0 (LevenbergMarquardt.jl) or 1 (lm.jl)");
+    return BA_ERR_ARG;
+  }
+  if (o->facto != 0 && o->facto != 1) {
+    ba_set_error("ba_lm_solve: facto must be 0 (:LDL) or 1 (:QR)");
     return BA_ERR_ARG;
   }
   if (o->normalize < 0 || o->normalize > 2) {
@@ -596,6 +611,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   const double delta_d = o->delta_d > 0 ? o->delta_d : 2;
   const int ite_max = o->ite_max >= 0 ? o->ite_max : (V ? 200 : 100);
   const bool linesearch = V && o->linesearch;
+  const bool facto_qr = o->facto == 1;  // same device solve; the branches differ in the line search's model value only
 
   memset(stats, 0, sizeof *stats);
   stats->status = BA_ST_UNKNOWN;
@@ -654,10 +670,15 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
       pred = obj - dr2;
       ared = obj - obj_suiv;
       step_accepted = ared >= 1e-4 * pred;  // lm.jl:257-259
+      double c_r = 1.0;  // delta_r = -(J delta + c_r r)
       while (linesearch && !step_accepted && ntimes < 4) {  // lm.jl:264-295
-        // delta /= delta_d ; delta_r = (delta_r - r)/delta_d (lm.jl:277) is again -(J delta + r) for the new delta
+        // delta /= delta_d ; delta_r = (delta_r - r)/delta_d (lm.jl:277): with delta_r = -(J delta + c r) the update is
+        // c <- (c + 1)/delta_d, which stays 1 only for the default delta_d = 2 (the reference's comment at lm.jl:275-276
+        // assumes it; the code is followed, not the comment)
+        // The :QR branch recomputes |J delta + r|^2 instead (lm.jl:273): c stays 1 there.
+        if (!facto_qr) c_r = (c_r + 1.0) / delta_d;
         if ((rc = launch_scale_scalar(p, w->nvar, w->delta, 1.0 / delta_d, st)) != BA_OK) break;
-        if ((rc = step_scalars(p, w, st)) != BA_OK) break;
+        if ((rc = step_scalars(p, w, st, c_r)) != BA_OK) break;
         if ((rc = trial_point(p, w, st, xf32)) != BA_OK) break;
         stats->n_residual++;
         if ((rc = comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st)) != BA_OK) break;

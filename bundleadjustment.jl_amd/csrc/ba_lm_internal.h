@@ -44,7 +44,7 @@ int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const 
 int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,
                    double *d_dp, hipStream_t st);
 int launch_model_sq(ba_problem *p, const double *d_J, const double *d_r, const double *d_delta, double *d_partial,
-                    double *d_scal, int slot, hipStream_t st);
+                    double *d_scal, int slot, hipStream_t st, double cr = 1.0);
 int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial, double *d_scal, int slot,
                  hipStream_t st);
 int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st);

@@ -339,14 +339,14 @@ __global__ __launch_bounds__(BLK) void k_backsub(int64_t npnts, const int *__res
 __global__ __launch_bounds__(BLK) void k_model_sq(int64_t nobs, int64_t npnts, const int *__restrict__ cam0,
                                                    const int *__restrict__ pnt0, const double *__restrict__ J,
                                                    const double *__restrict__ r, const double *__restrict__ delta,
-                                                   double *__restrict__ partial) {
+                                                   double cr, double *__restrict__ partial) {
   __shared__ double red[BLK / 64];
   double acc = 0;
   for (int64_t o = (int64_t)blockIdx.x * BLK + threadIdx.x; o < nobs; o += (int64_t)gridDim.x * BLK) {
     const double *Jo = J + 24 * o;
     const double *dp = delta + 3 * (int64_t)pnt0[o];
     const double *dcm = delta + 3 * npnts + 9 * (int64_t)cam0[o];
-    double s0 = r[2 * o], s1 = r[2 * o + 1];
+    double s0 = cr * r[2 * o], s1 = cr * r[2 * o + 1];  // cr == 1 except inside the line search with delta_d != 2
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       s0 += Jo[i] * dp[i];
@@ -504,15 +504,15 @@ int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const
   return BA_OK;
 }
 
-// |J delta + r|^2 -> scal[slot]
+// |J delta + cr r|^2 -> scal[slot]
 int launch_model_sq(ba_problem *p, const double *d_J, const double *d_r, const double *d_delta, double *d_partial,
-                    double *d_scal, int slot, hipStream_t st) {
+                    double *d_scal, int slot, hipStream_t st, double cr) {
   ProfScope ps(p, PC_TRIAL, st);
   int nb = (int)((p->nobs + BLK - 1) / BLK);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_model_sq, dim3(nb), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_J, d_r, d_delta,
-                     d_partial);
+                     cr, d_partial);
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLK), 0, st, nb, d_partial, d_scal, slot);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;

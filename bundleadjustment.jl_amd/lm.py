@@ -108,12 +108,14 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
     return out
 
 
-def lm_step(nlp, x, lam, want_jtr=True):
-    """One linear LM step from (x, lambda): delta, 1/2|J delta + r|^2, J'r  (ba_lm_step)."""
+def lm_step(nlp, x, lam, want_jtr=True, facto_type=None):
+    """One linear LM step from (x, lambda): delta, 1/2|J delta + r|^2, J'r  (ba_lm_step; facto_type=np.float32:
+    ba_lm_step_f32, the reduced camera system factored in Float32 as src/lm.jl:170-173 does)."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     delta = np.empty(nlp.meta.nvar)
     jtr = np.empty(nlp.meta.nvar) if want_jtr else None
     half = C.c_double(0)
-    _lib.check(_lib.lib().ba_lm_step(nlp.handle, _lib.ptr(x), float(lam), _lib.ptr(delta), C.byref(half),
-                                     _lib.ptr(jtr) if want_jtr else None))
+    f32 = facto_type is not None and np.dtype(facto_type) == np.float32
+    fn = _lib.lib().ba_lm_step_f32 if f32 else _lib.lib().ba_lm_step
+    _lib.check(fn(nlp.handle, _lib.ptr(x), float(lam), _lib.ptr(delta), C.byref(half), _lib.ptr(jtr) if want_jtr else None))
     return delta, half.value, jtr

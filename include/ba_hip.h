@@ -116,7 +116,9 @@ int ba_synchronize(ba_problem *p);
  * src/LevenbergMarquardt.jl:21-26). */
 typedef struct ba_lm_opts {
   int variant;    /* 0 LevenbergMarquardt.jl, 1 lm.jl */
-  int facto;      /* 0 :LDL, 1 :QR (same device solve) */
+  int facto;      /* 0 :LDL, 1 :QR -- both are served by the same device solve of (J'J + lambda I) delta = -J'r; what
+                   *    survives of the branch: inside the line search :QR re-evaluates |J delta + r|^2 (src/lm.jl:273)
+                   *    while :LDL uses the recursion of src/lm.jl:277 (they differ for delta_d != 2) */
   int normalize;  /* 0 :None, 1 :J, 2 :A  (src/lma_aux.jl:102-178) */
   int linesearch; /* lm.jl only, src/lm.jl:264-295 */
   int facto_f32;  /* lm.jl only: facto_type = Float32 (src/lm.jl:170-173, src/diffprecsions.jl:39-41) */
@@ -166,6 +168,10 @@ int ba_lm_set_comm(ba_problem *p, int rank, int world, double *d_reduce_buf, int
  * (== 1/2 |delta_r|^2 of the reference's augmented solve, src/lm.jl:229). */
 int ba_lm_step(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
                double *jtr /* nvar or NULL */);
+/* the same step with facto_type = Float32 (src/lm.jl:170-173, src/diffprecsions.jl:39-41): the reduced camera system is
+ * rounded to Float32, factored and solved there; everything else stays Float64 */
+int ba_lm_step_f32(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
+                   double *jtr /* nvar or NULL */);
 
 /* ---- per-kernel timing (hipEvent pairs on the handle's stream) ------------------------------------ */
 int ba_profile_enable(ba_problem *p, int on);

@@ -27,7 +27,7 @@ class LMOpts(C.Structure):
                 ("restol", C.c_double), ("satol", C.c_double), ("srtol", C.c_double), ("oatol", C.c_double),
                 ("ortol", C.c_double), ("atol", C.c_double), ("rtol", C.c_double),
                 ("nu_d", C.c_double), ("nu_m", C.c_double), ("lam", C.c_double), ("delta_d", C.c_double),
-                ("facto_time_cap_s", C.c_double), ("max_iter_timed", C.c_int)]
+                ("facto_time_cap_s", C.c_double), ("max_iter_timed", C.c_int), ("facto_qr", C.c_int)]
 
 
 class LMStats(C.Structure):
@@ -79,6 +79,8 @@ def lib():
     L.orc_lm_step.argtypes = [C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f64p, f64p, C.c_double, f64p,
                               C.c_void_p, C.c_void_p]
     L.orc_lm_step.restype = C.c_int
+    L.orc_qr_lstsq.argtypes = [C.c_int64, C.c_int64, f64p, f64p]
+    L.orc_qr_lstsq.restype = C.c_int
     _LIB = L
     return L
 
@@ -162,6 +164,16 @@ def ldl_solve(colptr, rowval, nzval, P, b):
     return rc, x, lnz.value, D
 
 
+def qr_lstsq(A, b):
+    """argmin |A x - b| by the dense Householder QR that stands in for SPQR (myqr + solve_qr!, src/qr_aux.jl:13-55)."""
+    A = np.asarray(A, dtype=np.float64)
+    m, n = A.shape
+    Af = np.ascontiguousarray(A.T).copy()  # column-major m x n
+    bb = _f64(b).copy()
+    rc = lib().orc_qr_lstsq(m, n, Af.reshape(-1), bb)
+    return rc, bb[:n]
+
+
 def lm_step(ncams, npnts, cam_idx1, pnt_idx1, pt2d, x, lam):
     nobs = len(cam_idx1)
     nvar = 9 * ncams + 3 * npnts
@@ -174,14 +186,16 @@ def lm_step(ncams, npnts, cam_idx1, pnt_idx1, pt2d, x, lam):
 
 
 def lm_solve(ncams, npnts, cam_idx1, pnt_idx1, pt2d, x0, variant=1, normalize=0, linesearch=False, facto_f32=False,
-             ite_max=-1, lam=-1.0, facto_time_cap_s=0.0, max_iter_timed=0, log_cap=512, **tols):
-    """Levenberg_Marquardt(...) of lm.jl (variant=1) or LevenbergMarquardt.jl (variant=0), :LDL branch."""
+             ite_max=-1, lam=-1.0, facto_time_cap_s=0.0, max_iter_timed=0, log_cap=512, facto="LDL", **tols):
+    """Levenberg_Marquardt(...) of lm.jl (variant=1) or LevenbergMarquardt.jl (variant=0); facto="QR": the :QR branch of
+    lm.jl with a dense Householder QR (small problems only: the matrix is densified)."""
     nobs = len(cam_idx1)
     o = LMOpts(variant=variant, normalize=normalize, linesearch=int(linesearch), facto_f32=int(facto_f32),
                ite_max=ite_max, restol=tols.get("restol", -1.0), satol=tols.get("satol", -1.0),
                srtol=tols.get("srtol", -1.0), oatol=tols.get("oatol", -1.0), ortol=tols.get("ortol", -1.0),
-               atol=tols.get("atol", -1.0), rtol=tols.get("rtol", -1.0), nu_d=-1.0, nu_m=-1.0, lam=lam,
-               delta_d=-1.0, facto_time_cap_s=facto_time_cap_s, max_iter_timed=max_iter_timed)
+               atol=tols.get("atol", -1.0), rtol=tols.get("rtol", -1.0), nu_d=tols.get("nu_d", -1.0),
+               nu_m=tols.get("nu_m", -1.0), lam=lam, delta_d=tols.get("delta_d", -1.0), facto_time_cap_s=facto_time_cap_s, max_iter_timed=max_iter_timed,
+               facto_qr=int(facto == "QR"))
     st = LMStats()
     x = _f64(x0).copy()
     log = np.zeros((log_cap, 8))

@@ -211,3 +211,37 @@ def test_runtests_least_squares_solve(orc):
         rc, x, lnz, D = orc.ldl_solve(colptr, rowval, nzval, np.arange(m + n, dtype=np.int64), rhs)
         assert rc == 0
         assert np.linalg.norm(x[m:] - true_x) < 1e-10
+
+
+def test_runtests_qr_solve(orc):
+    """runtests.jl:111-128 itself: x from the QR of A = [J; sqrt(lambda) I] equals A \\ b to 1e-10.  The oracle's dense
+    Householder QR (orc_qr_lstsq) stands in for myqr + solve_qr! (SuiteSparse SPQR is not in the image)."""
+    for seed in range(20):
+        rng = np.random.default_rng(700 + seed)
+        m, n, lam = 7, 5, 1.5
+        rj = rng.integers(1, m + 1, 8)
+        cj = rng.integers(1, n + 1, 8)
+        vj = _rand_half(rng, 8)
+        b = _rand_half(rng, m + n)
+        J = np.zeros((m, n))
+        np.add.at(J, (rj - 1, cj - 1), vj)
+        A = np.vstack([J, np.sqrt(lam) * np.eye(n)])
+        rc, x = orc.qr_lstsq(A, b)
+        assert rc == 0
+        assert np.linalg.norm(x - np.linalg.lstsq(A, b, rcond=None)[0]) < 1e-10
+
+
+def test_oracle_qr_branch_equals_ldl_branch(orc, ba):
+    """lm.jl's :QR and :LDL branches solve the same damped least-squares problem: on a small problem the two oracle runs
+    must take the same iterations (this is what lets one device solve serve both)."""
+    p = ba.synthetic.make_problem(6, 80, 320, seed=9)
+    for code in (0, 1, 2):
+        out = []
+        for facto in ("LDL", "QR"):
+            rc, x, st, log = orc.lm_solve(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"],
+                                          variant=1, normalize=code, facto=facto)
+            assert rc == 0
+            out.append((st.iter, st.status, st.objective, log[:, 1].copy()))
+        assert out[0][:2] == out[1][:2]
+        assert abs(out[0][2] - out[1][2]) <= 1e-10 * out[0][2]
+        assert np.allclose(out[0][3], out[1][3], rtol=1e-8)
