@@ -196,7 +196,9 @@ def main():
             # one launch per panel pair (k, k+1), k even: S_ij -= V0_i L_jk' + V1_i L_j,k+1' for the m(m+1)/2 lower tiles
             # right of tile column k+1, m = nt-k-2: 2 tile products of 2*128^3 flop each (kernel table)
             nt = (9 * ncams + 127) // 128
-            tiles = sum((nt - k - 2) * (nt - k - 1) // 2 for k in range(0, nt - 2, 2) if nt - k - 2 > 0)
+            # N > 1: the factorisation is distributed, a rank updates the tile columns it owns (pairs q with q % N == rank)
+            own = [j for j in range(nt) if (j // 2) % world == rank]
+            tiles = sum(sum(nt - j for j in own if j >= k + 2) for k in range(0, nt - 2, 2))
             flops = n_fact * tiles * 2 * 2.0 * 128 ** 3
             ach = flops / (ms * 1e-3) / 1e12
             peak_tf = MFMA_F64_PEAK_TF if args.facto_type == "f64" else MFMA_F32_PEAK_TF
@@ -293,7 +295,9 @@ def main():
             "config": {"workload": f"{args.workload} shape: ncams={ncams} npnts={npnts_g} nobs={nobs_g}, seed "
                                    f"{ba.synthetic.BASE_SEED}, lm.jl variant, LDL/None, facto_type {args.facto_type}, fixed {args.steps} iterations"
                                    + ("" if args.scale == 1.0 else f" SCALED x{args.scale} (debug)"),
-                       "parallelism": f"points sharded over {world} rank(s), cameras replicated"},
+                       "parallelism": f"points sharded over {world} rank(s), cameras replicated"
+                                      + ("" if world == 1 else "; reduced camera matrix reduced onto the owners of its tile column "
+                                         "pairs, factorisation distributed (panel broadcast), solves replicated")},
             "jacobian_mnnz_per_s": jac_mnnz,
             "jacobian_ms": jac_ms,
             "lm": {"accepted": st.n_accepted, "rejected": st.n_rejected, "objective": st.objective,
@@ -306,8 +310,9 @@ def main():
             "setup_s": t_setup,
         }
         if reducer is not None:
-            out["comm"] = {"allreduce_calls": reducer.calls, "allreduce_bytes": reducer.bytes,
-                           "allreduce_ms_profiled_run": prof.get("allreduce", (None, 0))[0]}
+            out["comm"] = {"transport": "rccl (called from the library)" if args.backend == "nccl" else "hook over " + args.backend,
+                           "calls": reducer.calls, "bytes": reducer.bytes,
+                           "ms_profiled_run": prof.get("allreduce", (None, 0))[0]}
         print(json.dumps(out))
     nlp.close()
     if world > 1:

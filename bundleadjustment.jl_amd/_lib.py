@@ -43,7 +43,9 @@ class LMStats(C.Structure):
 
 LOG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                      C.c_double, C.c_int)
-ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)
+COMM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+COMM_ALLREDUCE_F64, COMM_REDUCE_F64, COMM_BCAST_BYTES = 0, 1, 2
+COMM_ID_BYTES = 128
 
 # every symbol include/ba_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -51,7 +53,8 @@ SYMBOLS = [
     "ba_problem_create", "ba_problem_destroy", "ba_problem_dims", "ba_residual", "ba_residual_f32",
     "ba_jac_structure", "ba_jac_coord", "ba_jac_coord_f32", "ba_jtr", "ba_residual_dev", "ba_residual_f32_dev",
     "ba_jac_structure_dev", "ba_jac_coord_dev", "ba_jac_coord_f32_dev", "ba_jtr_dev", "ba_dev_malloc", "ba_dev_free",
-    "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_synchronize", "ba_lm_solve", "ba_lm_reduce_doubles", "ba_lm_set_comm",
+    "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_synchronize", "ba_lm_solve", "ba_comm_get_unique_id", "ba_lm_set_comm_rccl",
+    "ba_lm_set_comm_hook", "ba_comm_stats", "ba_dist_layout",
     "ba_lm_step", "ba_lm_step_f32", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
 ]
 
@@ -90,8 +93,11 @@ def lib():
     L.ba_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     L.ba_synchronize.argtypes = [vp]
     L.ba_lm_solve.argtypes = [vp, C.POINTER(LMOpts), vp, C.POINTER(LMStats), LOG_CB, vp]
-    L.ba_lm_reduce_doubles.argtypes = [vp, C.POINTER(i64)]
-    L.ba_lm_set_comm.argtypes = [vp, C.c_int, C.c_int, vp, i64, ALLREDUCE_CB, vp]
+    L.ba_comm_get_unique_id.argtypes = [vp]
+    L.ba_lm_set_comm_rccl.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.ba_lm_set_comm_hook.argtypes = [vp, C.c_int, C.c_int, COMM_CB, vp]
+    L.ba_comm_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.ba_dist_layout.argtypes = [i64, C.c_int, vp, vp]
     L.ba_lm_step.argtypes = [vp, vp, f64, vp, C.POINTER(f64), vp]
     L.ba_lm_step_f32.argtypes = [vp, vp, f64, vp, C.POINTER(f64), vp]
     L.ba_profile_enable.argtypes = [vp, C.c_int]

@@ -158,6 +158,7 @@ extern "C" void ba_problem_destroy(ba_problem *p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   lm_free(p);
+  comm_free(p);
   void *ptrs[] = {p->cam0, p->pnt0, p->pt2d, p->pt2d_f32, p->pt_ptr, p->pt_obs, p->cam_ptr, p->cam_obs,
                   p->scratch[0], p->scratch[1], p->scratch[2], p->scratch[3]};
   for (void *q : ptrs)

@@ -16,6 +16,7 @@
 // Solves: forward substitution fused into the panel solves, diagonal scaling folded into the backward sweep by tile rows.
 #include "ba_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -513,7 +514,7 @@ __device__ inline void tile_gemm_rows(const T *__restrict__ A, const T *__restri
 // rows [32 rq, 32 rq + 32) of X_i = S_ik Linv_k' -> V_i, S_ik = X_i D_k^-1; FWD: y_k and b_i -= L_ik y_k ride along.
 // grid = 4 (nt-k-1): i = k + 1 + blockIdx.x / 4, rq = blockIdx.x % 4
 template <typename T, bool FWD>
-__global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const T *__restrict__ Linv_k,
+__global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv_k,
                                                       const T *__restrict__ D_k, T *__restrict__ V, int k,
                                                       T *__restrict__ b, T *__restrict__ y) {
   BA_VT
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const T 
   T *lds = reinterpret_cast<T *>(smraw);
   T *sA = lds, *sB = lds + RS * LDK, *ysh = lds + (RS + NB) * LDK, *red = ysh + NB;  // red: 4 x 32
   const int i = k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
-  T *Sik = S + tile_index(i, k) * NB * NB + r0 * NB;
+  T *Sik = S + tix(co, i, k) * NB * NB + r0 * NB;
   T *Vi = V + (int64_t)i * NB * NB + r0 * NB;
   typename RT<T>::v4 acc[2][2];
 #pragma unroll
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const T 
 
 // rows [32 rq, 32 rq + 32) of S_{i,k+1} -= V0_i L_{k+1,k}'   (grid = 4 (nt-k-1))
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const T *__restrict__ V0, int k) {
+__global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, int k) {
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
@@ -589,9 +590,9 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const T *
   for (int m = 0; m < 2; m++)
 #pragma unroll
     for (int n = 0; n < 2; n++) acc[m][n] = (d4){0, 0, 0, 0};
-  tile_gemm_rows<T, false>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tile_index(k + 1, k) * NB * NB, sA, sB, acc, nullptr, nullptr);
+  tile_gemm_rows<T, false>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tix(co, k + 1, k) * NB * NB, sA, sB, acc, nullptr, nullptr);
   const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) * 32;
-  T *Sij = S + tile_index(i, k + 1) * NB * NB + r0 * NB;
+  T *Sij = S + tix(co, i, k + 1) * NB * NB + r0 * NB;
 #pragma unroll
   for (int n = 0; n < 2; n++) {
     const int col = wc + 16 * n + (lane & 15);
@@ -616,10 +617,15 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const T *
 // (delaying every CU's second workgroup by 10 / 20 / 34 us changed nothing: 59.6-59.9); the read-modify-write epilogue
 // and the operands' home (variants 1, 2).  What is left is the staging inside the loop: every wave pulls its own A and B
 // slices, 16 KB per 64 MFMAs, ~9.7 TB/s of L2 -> LDS traffic chip-wide, with a wait for it at every chunk boundary.
-template <typename T, int MODE, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const T *__restrict__ V0,
+// OWN (distributed factorisation): the launch covers only the tile columns this rank owns, listed ascending in own_cols
+// with own_pref[m] = number of tiles in the columns before own_cols[m]; the columns >= base start at index m0.
+template <typename T, int MODE, int DBG = 0, bool OWN = false>
+__global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
                                                         const T *__restrict__ V1, int k, int base, int nt,
-                                                        int nblk, int *__restrict__ ready) {
+                                                        int nblk, int *__restrict__ ready,
+                                                        const int *__restrict__ own_cols = nullptr,
+                                                        const int64_t *__restrict__ own_pref = nullptr, int m0 = 0,
+                                                        int m_end = 0) {
   BA_VT
   static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -632,14 +638,26 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
     const int per = (nblk + 7) / 8;
     int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (t >= nblk) return;
-    int ii = (int)((sqrt(8.0 * (T)t + 1.0) - 1.0) * 0.5);
-    while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-    while (ii * (ii + 1) / 2 > t) ii--;
-    const int jj = t - ii * (ii + 1) / 2;
-    i = base + ii;
-    j = base + jj;
+    if (OWN) {
+      const int64_t tt = t + own_pref[m0];
+      int lo = m0, hi = m_end;  // largest m with own_pref[m] <= tt
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (own_pref[mid] <= tt) lo = mid;
+        else hi = mid;
+      }
+      j = own_cols[lo];
+      i = j + (int)(tt - own_pref[lo]);
+    } else {
+      int ii = (int)((sqrt(8.0 * (T)t + 1.0) - 1.0) * 0.5);
+      while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+      while (ii * (ii + 1) / 2 > t) ii--;
+      const int jj = t - ii * (ii + 1) / 2;
+      i = base + ii;
+      j = base + jj;
+    }
   }
-  T *Sij = S + tile_index(i, j) * NB * NB;
+  T *Sij = S + tix(co, i, j) * NB * NB;
   typename RT<T>::v4 acc[4][4];
 #pragma unroll
   for (int m = 0; m < 4; m++)
@@ -647,11 +665,11 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
     for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
   const int io = (DBG & 2) ? base : i, jo = (DBG & 2) ? base : j;
   if (!(DBG & 8))
-    tile_gemm_abt_priv<T, 2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
-                          S + tile_index(jo, k + 1) * NB * NB, lds, acc);
+    tile_gemm_abt_priv<T, 2>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                          S + tix(co, jo, k + 1) * NB * NB, lds, acc);
   else
-    tile_gemm_abt<T, 2>(V0 + (int64_t)io * NB * NB, S + tile_index(jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
-                     S + tile_index(jo, k + 1) * NB * NB, sA, sB, acc);
+    tile_gemm_abt<T, 2>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                     S + tix(co, jo, k + 1) * NB * NB, sA, sB, acc);
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
   const int lane = tid2 & 63, wv = tid2 >> 6;
@@ -688,6 +706,29 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
   }
 }
 
+// ---- distributed factorisation helpers -----------------------------------------------------------------------------------
+// A rank that received the panel V = L D of tile column k from its owner rebuilds L_ik = V_i D_k^-1 in its own copy of S
+// (rows i0..nt-1), with the owner's arithmetic (k_ldl_trsm_rs: xv * (1 / d)), so that every rank holds the same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_scale_panel(T *__restrict__ S, const int64_t *__restrict__ co,
+                                                          const T *__restrict__ V, const T *__restrict__ D_k, int k, int i0) {
+  BA_VT
+  const int i = i0 + blockIdx.x;
+  const T *Vi = V + (int64_t)i * NB * NB;
+  T *Sik = S + tix(co, i, k) * NB * NB;
+  const int c2 = threadIdx.x & 63;  // this thread's column pair (2 c2, 2 c2 + 1), the same in every row it touches
+  const T inv0 = (T)1 / D_k[2 * c2], inv1 = (T)1 / D_k[2 * c2 + 1];
+  for (int r = threadIdx.x >> 6; r < NB; r += 4) {
+    d2 v = *reinterpret_cast<const d2 *>(Vi + r * NB + 2 * c2);
+    v.x *= inv0;
+    v.y *= inv1;
+    *reinterpret_cast<d2 *>(Sik + r * NB + 2 * c2) = v;
+  }
+}
+
+__global__ void k_flag_to_double(const int *flag, double *out) { out[0] = (double)(flag[0] != 0); }
+__global__ void k_double_to_flag(const double *in, int *flag) { if (in[0] != 0.0) flag[0] = 1; }
+
 // ---- triangular solves -------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ inline T wsum(T v) {
@@ -698,7 +739,7 @@ __device__ inline T wsum(T v) {
 
 // forward step k: y_k = Linv_k b_k (every workgroup recomputes it; block 0 stores it), then b_i -= L_ik y_k, i > k.
 template <typename T>
-__global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const T *__restrict__ Linv,
+__global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
                                                    T *__restrict__ b, T *__restrict__ y, int k) {
   BA_VT
   __shared__ T yk[NB];
@@ -717,7 +758,7 @@ __global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const
     return;
   }
   const int i = k + blockIdx.x;
-  const T *Lik = S + tile_index(i, k) * NB * NB;
+  const T *Lik = S + tix(co, i, k) * NB * NB;
   const T y0 = yk[2 * lane], y1 = yk[2 * lane + 1];
   for (int rr = 0; rr < 32; rr++) {
     int row = wv * 32 + rr;
@@ -730,7 +771,7 @@ __global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const
 // backward step k: x_k = Linv_k' z_k with z = y / D (every workgroup recomputes it; block 0 stores it into b_k),
 // then y_j -= D_j (L_kj' x_k) ... expressed on z: z_j -= L_kj' x_k, i.e. y_j -= D_j * (L_kj' x_k), j < k.
 template <typename T>
-__global__ __launch_bounds__(256) void k_bwd_step(const T *__restrict__ S, const T *__restrict__ Linv,
+__global__ __launch_bounds__(256) void k_bwd_step(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
                                                    const T *__restrict__ D, T *__restrict__ y,
                                                    T *__restrict__ x, int k) {
   BA_VT
@@ -753,7 +794,7 @@ __global__ __launch_bounds__(256) void k_bwd_step(const T *__restrict__ S, const
     return;
   }
   const int j = blockIdx.x - 1;  // 0 .. k-1
-  const T *Lkj = S + tile_index(k, j) * NB * NB;
+  const T *Lkj = S + tix(co, k, j) * NB * NB;
   T s = 0;
   for (int r = half * 64; r < half * 64 + 64; r++) s += Lkj[r * NB + c] * xk[r];
   part[half][c] = s;
@@ -777,24 +818,52 @@ static int set_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 1>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 0, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 8>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 9>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
   g_attr_done = true;
   return BA_OK;
 }
 
+void dense_ldl_layout(int64_t nt, int world, std::vector<int64_t> *col_off, std::vector<int64_t> *own_range) {
+  col_off->assign((size_t)nt, 0);
+  if (own_range) own_range->assign((size_t)world + 1, 0);
+  int64_t off = 0;
+  for (int r = 0; r < world; r++) {
+    if (own_range) (*own_range)[(size_t)r] = off;
+    for (int64_t q = r; 2 * q < nt; q += world)
+      for (int64_t j = 2 * q; j < 2 * q + 2 && j < nt; j++) {
+        (*col_off)[(size_t)j] = off;
+        off += nt - j;
+      }
+  }
+  if (own_range) (*own_range)[(size_t)world] = off;
+}
+
 template <typename T>
-int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S) {
+int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world, int rank) {
   int64_t nt = (n_unpadded + NB - 1) / NB;
   if (nt < 1) nt = 1;
   w->n = nt * NB;
   w->nt = nt;
+  w->world = world;
+  w->rank = rank;
+  dense_ldl_layout(nt, world, &w->h_col_off, &w->own_range);
+  BA_HIP_CHECK(hipMalloc((void **)&w->col_off, (size_t)nt * sizeof(int64_t)));
+  BA_HIP_CHECK(hipMemcpy(w->col_off, w->h_col_off.data(), (size_t)nt * sizeof(int64_t), hipMemcpyHostToDevice));
+  // the tile columns this rank owns (pairs q with q % world == rank), ascending, with running tile counts
+  w->h_own_cols.clear();
+  w->h_own_pref.assign(1, 0);
+  for (int64_t j = 0; j < nt; j++)
+    if ((j / 2) % world == rank) {
+      w->h_own_cols.push_back((int)j);
+      w->h_own_pref.push_back(w->h_own_pref.back() + (nt - j));
+    }
+  BA_HIP_CHECK(hipMalloc((void **)&w->own_cols, (w->h_own_cols.size() + 1) * sizeof(int)));
+  BA_HIP_CHECK(hipMalloc((void **)&w->own_pref, w->h_own_pref.size() * sizeof(int64_t)));
+  if (!w->h_own_cols.empty())
+    BA_HIP_CHECK(hipMemcpy(w->own_cols, w->h_own_cols.data(), w->h_own_cols.size() * sizeof(int), hipMemcpyHostToDevice));
+  BA_HIP_CHECK(hipMemcpy(w->own_pref, w->h_own_pref.data(), w->h_own_pref.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  BA_HIP_CHECK(hipMalloc((void **)&w->flag_sum, sizeof(double)));
   if (external_S) {
     w->S = external_S;
     w->own_S = false;
@@ -822,6 +891,10 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->Linv) (void)hipFree(w->Linv);
   if (w->D) (void)hipFree(w->D);
   if (w->flag) (void)hipFree(w->flag);
+  if (w->col_off) (void)hipFree(w->col_off);
+  if (w->own_cols) (void)hipFree(w->own_cols);
+  if (w->own_pref) (void)hipFree(w->own_pref);
+  if (w->flag_sum) (void)hipFree(w->flag_sum);
   if (w->ready) (void)hipFree(w->ready);
   if (w->hoist) (void)hipStreamDestroy(w->hoist);
   if (w->ev_top) (void)hipEventDestroy(w->ev_top);
@@ -832,7 +905,7 @@ void dense_ldl_free(DenseLDLT<T> *w) {
 template <typename T>
 static int launch_diag(ba_problem *p, DenseLDLT<T> *w, int k, hipStream_t st, const int *wait_ready = nullptr) {
   ProfScope ps(p, PC_LDL_DIAG, st);
-  hipLaunchKernelGGL(k_ldl_diag<T>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(T), st, w->S + tile_index(k, k) * NB * NB,
+  hipLaunchKernelGGL(k_ldl_diag<T>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(T), st, w->S + tix(w->h_col_off.data(), k, k) * NB * NB,
                      w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag, (unsigned long long *)nullptr,
                      wait_ready);
   return BA_OK;
@@ -845,15 +918,15 @@ static int launch_trsm(ba_problem *p, DenseLDLT<T> *w, int k, T *V, T *b, hipStr
   const int m = (int)w->nt - k - 1;
   T *y = w->D + w->nt * NB;
   if (m <= 0) {
-    if (b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, st, w->S, w->Linv, b, y, k);
+    if (b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, st, w->S, w->col_off, w->Linv, b, y, k);
     return BA_OK;
   }
   ProfScope ps(p, PC_LDL_TRSM, st);
   if (b)
-    hipLaunchKernelGGL((k_ldl_trsm_rs<T, true>), dim3(4 * m), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->Linv + (int64_t)k * NB * NB,
+    hipLaunchKernelGGL((k_ldl_trsm_rs<T, true>), dim3(4 * m), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, w->Linv + (int64_t)k * NB * NB,
                        w->D + (int64_t)k * NB, V, k, b, y);
   else
-    hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * m), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->Linv + (int64_t)k * NB * NB,
+    hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * m), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, w->Linv + (int64_t)k * NB * NB,
                        w->D + (int64_t)k * NB, V, k, b, y);
   return BA_OK;
 }
@@ -863,7 +936,7 @@ static int launch_col(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0, hipStr
   const int m = (int)w->nt - k - 1;
   if (m <= 0) return BA_OK;
   ProfScope ps(p, PC_LDL_SYRK, st);
-  hipLaunchKernelGGL(k_ldl_col_rs<T>, dim3(4 * m), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, V0, k);
+  hipLaunchKernelGGL(k_ldl_col_rs<T>, dim3(4 * m), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, V0, k);
   return BA_OK;
 }
 
@@ -877,7 +950,7 @@ static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, const T 
   ProfScope ps(p, PC_LDL_UPDATE, st);
   const int nblk = m * (m + 1) / 2;
   hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st, w->S,
-                     V0, V1, k, base, nt, nblk, ready);
+                     w->col_off, V0, V1, k, base, nt, nblk, ready);
   return BA_OK;
 }
 
@@ -905,7 +978,7 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
   // the model's break-even is nt ~ 250.
   constexpr int HOIST_MAX_TILES = 224;
   static const bool hoist_off = [] { const char *e = getenv("BA_LDL_HOIST"); return e && e[0] == '0'; }();
-  w->hoisting = !p->prof_on && !hoist_off && !w->hoist_disabled && nt >= HOIST_MIN_TILES + 2 && nt <= HOIST_MAX_TILES;
+  w->hoisting = !p->prof_on && !hoist_off && !w->hoist_disabled && !p->comm.active() && nt >= HOIST_MIN_TILES + 2 && nt <= HOIST_MAX_TILES;
   if (w->hoisting) {
     BA_HIP_CHECK(hipMemsetAsync(w->ready, 0, (size_t)nt * sizeof(int), st));
     // one fork for the whole factorisation: the hoisted kernels only depend on their flags (and on stream order among
@@ -944,6 +1017,77 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
   return BA_OK;
 }
 
+// pair update restricted to the tile columns >= base that this rank owns
+template <typename T>
+static int launch_pair_owned(ba_problem *p, DenseLDLT<T> *w, int k, int base, const T *V0, const T *V1, hipStream_t st) {
+  const int M = (int)w->h_own_cols.size();
+  const int m0 = (int)(std::lower_bound(w->h_own_cols.begin(), w->h_own_cols.end(), base) - w->h_own_cols.begin());
+  if (m0 >= M) return BA_OK;
+  const int64_t nblk64 = w->h_own_pref[(size_t)M] - w->h_own_pref[(size_t)m0];
+  if (nblk64 <= 0) return BA_OK;
+  const int nblk = (int)nblk64;
+  ProfScope ps(p, PC_LDL_UPDATE, st);
+  hipLaunchKernelGGL((k_ldl_update<T, 1, 0, true>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st,
+                     w->S, w->col_off, V0, V1, k, base, (int)w->nt, nblk, (int *)nullptr, w->own_cols, w->own_pref, m0, M);
+  return BA_OK;
+}
+
+// Distributed right-looking factorisation over the ranks of p->comm: tile column pair q = (2q, 2q+1) belongs to rank
+// q % world.  Per pair: the owner runs the panel chain of dense_ldl_factor on its (fully updated) columns, broadcasts
+// V = L D of both panels, the two inverted diagonal tiles and the 256 pivots; the other ranks rebuild L = V D^-1 in their
+// copy of S; every rank then applies the pair update (K = 256) to the tile columns it owns.  On exit every rank holds the
+// whole factor, so the triangular solves are replicated and bit-identical everywhere.  Traffic per rank: the panels,
+// n^2/2 elements in total (Venice, n = 16 002: 1.0 GB; Final-13682, n = 123 138: 60 GB Float64 / 30 GB Float32) against
+// n^3/(3 world) flops.  The hoisted-diagonal schedule is a single-GPU refinement and is not used here.
+template <typename T>
+int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
+  const int nt = (int)w->nt, P = w->world, me = w->rank;
+  const int64_t panel = (int64_t)nt * NB * NB;
+  T *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
+  BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
+  w->hoisting = false;
+  for (int k = 0, q = 0; k < nt; k += 2, q++) {
+    T *V0 = Vs[q & 1][0], *V1 = Vs[q & 1][1];
+    const int owner = q % P;
+    const bool two = k + 1 < nt;
+    if (owner == me) {
+      launch_diag(p, w, k, st);
+      launch_trsm(p, w, k, V0, (T *)nullptr, st);
+      if (two) {
+        launch_col(p, w, k, V0, st);
+        launch_diag(p, w, k + 1, st);
+        launch_trsm(p, w, k + 1, V1, (T *)nullptr, st);
+      }
+    }
+    BA_HIP_CHECK(hipGetLastError());
+    const int rows0 = nt - k - 1, rows1 = nt - k - 2;  // tile rows below the diagonal tile of column k / k + 1
+    BA_CHECK(comm_group_begin(p));
+    int rc = BA_OK;
+    if (rows0 > 0) rc = comm_bcast(p, V0 + (int64_t)(k + 1) * NB * NB, (int64_t)rows0 * NB * NB * sizeof(T), owner, st);
+    if (rc == BA_OK && two && rows1 > 0)
+      rc = comm_bcast(p, V1 + (int64_t)(k + 2) * NB * NB, (int64_t)rows1 * NB * NB * sizeof(T), owner, st);
+    if (rc == BA_OK) rc = comm_bcast(p, w->Linv + (int64_t)k * NB * NB, (int64_t)(two ? 2 : 1) * NB * NB * sizeof(T), owner, st);
+    if (rc == BA_OK) rc = comm_bcast(p, w->D + (int64_t)k * NB, (int64_t)(two ? 2 : 1) * NB * sizeof(T), owner, st);
+    BA_CHECK(comm_group_end(p));
+    BA_CHECK(rc);
+    if (owner != me) {
+      if (rows0 > 0)
+        hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows0), dim3(256), 0, st, w->S, w->col_off, V0, w->D + (int64_t)k * NB, k, k + 1);
+      if (two && rows1 > 0)
+        hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows1), dim3(256), 0, st, w->S, w->col_off, V1, w->D + (int64_t)(k + 1) * NB,
+                           k + 1, k + 2);
+    }
+    if (k + 2 >= nt) break;
+    BA_CHECK(launch_pair_owned(p, w, k, k + 2, V0, V1, st));
+  }
+  // an exactly zero pivot is seen by the owner of that tile only: make the flag collective
+  hipLaunchKernelGGL(k_flag_to_double, dim3(1), dim3(1), 0, st, w->flag, w->flag_sum);
+  BA_CHECK(comm_allreduce(p, w->flag_sum, 1, st));
+  hipLaunchKernelGGL(k_double_to_flag, dim3(1), dim3(1), 0, st, w->flag_sum, w->flag);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
 template <typename T>
 int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool forward_done) {
   const int nt = (int)w->nt;
@@ -951,9 +1095,9 @@ int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool
   ProfScope ps(p, PC_SOLVE, st);
   if (!forward_done)
     for (int k = 0; k < nt; k++)
-      hipLaunchKernelGGL(k_fwd_step<T>, dim3(nt - k), dim3(256), 0, st, w->S, w->Linv, d_b, y, k);
+      hipLaunchKernelGGL(k_fwd_step<T>, dim3(nt - k), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k);
   for (int k = nt - 1; k >= 0; k--)
-    hipLaunchKernelGGL(k_bwd_step<T>, dim3(k + 1), dim3(256), 0, st, w->S, w->Linv, w->D, y, d_b, k);
+    hipLaunchKernelGGL(k_bwd_step<T>, dim3(k + 1), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, k);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
@@ -978,7 +1122,7 @@ static int dense_solve_host(int device, int64_t n, const double *a_lower_rowmajo
     for (int64_t j = 0; j <= i; j++) {
       int64_t tj = j / NB;
       double v = (i < n) ? a_lower_rowmajor[i * n + j] : (i == j ? 1.0 : 0.0);
-      tiles[(size_t)((tile_index(ti, tj) * NB + (i - ti * NB)) * NB + (j - tj * NB))] = (T)v;
+      tiles[(size_t)((tix(w.h_col_off.data(), ti, tj) * NB + (i - ti * NB)) * NB + (j - tj * NB))] = (T)v;
     }
   }
   std::vector<T> bb((size_t)npad, (T)0);
@@ -1033,281 +1177,13 @@ extern "C" int ba_dense_ldl_solve_f32(int device, int64_t n, const double *a_low
   return dense_solve_host<float>(device, n, a_lower_rowmajor, b, x, factor_ms);
 }
 
-template int dense_ldl_alloc<double>(DenseLDLT<double> *, int64_t, double *);
-template int dense_ldl_alloc<float>(DenseLDLT<float> *, int64_t, float *);
+template int dense_ldl_alloc<double>(DenseLDLT<double> *, int64_t, double *, int, int);
+template int dense_ldl_alloc<float>(DenseLDLT<float> *, int64_t, float *, int, int);
 template void dense_ldl_free<double>(DenseLDLT<double> *);
 template void dense_ldl_free<float>(DenseLDLT<float> *);
 template int dense_ldl_factor<double>(ba_problem *, DenseLDLT<double> *, hipStream_t, int *, double *);
 template int dense_ldl_factor<float>(ba_problem *, DenseLDLT<float> *, hipStream_t, int *, float *);
+template int dense_ldl_factor_dist<double>(ba_problem *, DenseLDLT<double> *, hipStream_t);
+template int dense_ldl_factor_dist<float>(ba_problem *, DenseLDLT<float> *, hipStream_t);
 template int dense_ldl_solve<double>(ba_problem *, DenseLDLT<double> *, double *, hipStream_t, bool);
 template int dense_ldl_solve<float>(ba_problem *, DenseLDLT<float> *, float *, hipStream_t, bool);
-
-// micro-benchmark of the bulk trailing update (tools/bench_update.py): one pair update of an nt x nt tile matrix
-extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_out) {
-  BA_CHECK(set_kernel_attrs<double>());
-  const size_t tiles = (size_t)nt * (nt + 1) / 2 * NB * NB;
-  double *S = nullptr, *V = nullptr;
-  BA_HIP_CHECK(hipMalloc((void **)&S, tiles * sizeof(double)));
-  BA_HIP_CHECK(hipMalloc((void **)&V, (size_t)2 * nt * NB * NB * sizeof(double)));
-  BA_HIP_CHECK(hipMemset(S, 0, tiles * sizeof(double)));
-  BA_HIP_CHECK(hipMemset(V, 0, (size_t)2 * nt * NB * NB * sizeof(double)));
-  const int m = nt - 2, nblk = m * (m + 1) / 2, grid = ((nblk + 7) / 8) * 8;
-  hipEvent_t e0, e1;
-  BA_HIP_CHECK(hipEventCreate(&e0));
-  BA_HIP_CHECK(hipEventCreate(&e1));
-  auto launch = [&]() {
-    const double *V0 = V, *V1 = V + (size_t)nt * NB * NB;
-    switch (variant) {
-      case 1: hipLaunchKernelGGL((k_ldl_update<double, 1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      case 2: hipLaunchKernelGGL((k_ldl_update<double, 1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      case 8: hipLaunchKernelGGL((k_ldl_update<double, 1, 8>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      case 9: hipLaunchKernelGGL((k_ldl_update<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      default: hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, V0, V1, 0, 2, nt, nblk, (int *)nullptr);
-    }
-  };
-  {
-    int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_ldl_update<double, 1, 0>), 256, GEMM_LDS_ELEMS * sizeof(double));
-    if (variant == 0) fprintf(stderr, "[debug] update<1>: occupancy API says %d workgroups/CU at %zu B LDS\n", nb, GEMM_PRIV_LDS_ELEMS * sizeof(double));
-  }
-  launch();
-  BA_HIP_CHECK(hipDeviceSynchronize());
-  BA_HIP_CHECK(hipEventRecord(e0, 0));
-  for (int r = 0; r < reps; r++) launch();
-  BA_HIP_CHECK(hipEventRecord(e1, 0));
-  BA_HIP_CHECK(hipEventSynchronize(e1));
-  float ms = 0;
-  BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  *ms_out = ms / reps;
-  (void)hipFree(S);
-  (void)hipFree(V);
-  return BA_OK;
-}
-
-// diagnostic: phase cycle counts of the diagonal-tile kernel (load, pivots, inverse16, trsm16+syrk16, full inverse, store)
-extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
-  BA_CHECK(set_kernel_attrs<double>());
-  double *S = nullptr, *Li = nullptr, *D = nullptr;
-  int *flag = nullptr;
-  unsigned long long *st = nullptr;
-  BA_HIP_CHECK(hipMalloc((void **)&S, NB * NB * sizeof(double)));
-  BA_HIP_CHECK(hipMalloc((void **)&Li, NB * NB * sizeof(double)));
-  BA_HIP_CHECK(hipMemset(Li, 0, NB * NB * sizeof(double)));
-  BA_HIP_CHECK(hipMalloc((void **)&D, NB * sizeof(double)));
-  BA_HIP_CHECK(hipMalloc((void **)&flag, sizeof(int)));
-  BA_HIP_CHECK(hipMalloc((void **)&st, 6 * sizeof(unsigned long long)));
-  std::vector<double> h((size_t)NB * NB, 0.0);
-  for (int i = 0; i < NB; i++)
-    for (int j = 0; j <= i; j++) h[(size_t)i * NB + j] = (i == j) ? 300.0 + i : 1.0 / (1 + i + j);
-  hipEvent_t e0, e1;
-  BA_HIP_CHECK(hipEventCreate(&e0));
-  BA_HIP_CHECK(hipEventCreate(&e1));
-  float ms = 0;
-  for (int rep = 0; rep < 3; rep++) {
-    BA_HIP_CHECK(hipMemcpy(S, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
-    BA_HIP_CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(double), 0, S, Li, D, flag, rep == 2 ? st : nullptr, (const int *)nullptr);
-    BA_HIP_CHECK(hipEventRecord(e1, 0));
-    BA_HIP_CHECK(hipEventSynchronize(e1));
-    if (rep == 1) BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  }
-  unsigned long long hs[6];
-  BA_HIP_CHECK(hipMemcpy(hs, st, sizeof hs, hipMemcpyDeviceToHost));
-  for (int q = 0; q < 6; q++) cycles6[q] = (double)hs[q];
-  *ms_out = ms;
-  (void)hipFree(S); (void)hipFree(Li); (void)hipFree(D); (void)hipFree(flag); (void)hipFree(st);
-  return BA_OK;
-}
-
-// ---- MFMA ceiling probes (tools/bench_mfma_probe.py): how close a K loop of the update kernel's shape can get to the
-// f64 matrix peak.  MODE 0: MFMAs only, 4x4 accumulator blocks per wave, 2 waves per SIMD; MODE 1: the same with the
-// update kernel's LDS operand reads (8 ds_read_b64 per 16 MFMAs), no staging; MODE 2: 4x8 blocks per wave, one wave per
-// SIMD, no staging.  Modes 3 / 4 (k_stage_probe): the full wave-private staging loop (global -> registers -> LDS, chunks
-// of 16, next chunk's loads in flight during the MFMAs) on operands in global memory, K = 256 per "tile", 16 tiles per
-// persistent workgroup, no C tile traffic: 3 = the shipped geometry (64x64 per wave, 2 workgroups per CU), 4 = 64x128
-// per wave, 1 workgroup per CU.
-// Measured (TFLOP/s): 0: 78.0   1: 78.0   2: 58.6 (compiler spills)   3: 67.7-69.8   4: 64.3-65.1.
-// (Also tried in this probe: two LDS buffers of 8-wide chunks per wave at the same 73.7 KB, row stride 9 doubles: 43 --
-// the 72-byte rows break the 16-byte LDS writes.)
-// With them: the shipped kernel's 59.8 in tools/bench_update.py becomes 64-65 with a store-only epilogue (variant 1), and
-// reading the C tile costs the same 6-7 TFLOP/s wherever the loads are placed (end of tile, or start of tile into the
-// accumulators, with or without persistent workgroups): the pair update moves 2 x 0.98 GB of C per launch for 0.063
-// TFLOP, i.e. at K = 256 the trailing matrix's HBM traffic is a third of the kernel's time when it is not overlapped.
-namespace {
-template <int MODE>
-__global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void k_mfma_probe(double *out, int iters) {
-  typedef double d4p __attribute__((ext_vector_type(4)));
-  constexpr int NC = (MODE == 2) ? 8 : 4;
-  __shared__ double sm[(64 + 128) * 18];
-  for (int i = threadIdx.x; i < (64 + 128) * 18; i += 256) sm[i] = 1.0 + 1e-9 * i;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fk = lane >> 4;
-  d4p acc[4][NC];
-#pragma unroll
-  for (int m = 0; m < 4; m++)
-#pragma unroll
-    for (int n = 0; n < NC; n++) acc[m][n] = (d4p){0, 0, 0, 0};
-  double af[4], bf[NC];
-#pragma unroll
-  for (int m = 0; m < 4; m++) af[m] = 1.0 + lane * 1e-3 + m;
-#pragma unroll
-  for (int n = 0; n < NC; n++) bf[n] = 2.0 - lane * 1e-3 + n;
-  const double *sA = sm, *sB = sm + 64 * 18;
-  for (int it = 0; it < iters; it++) {
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      if (MODE >= 1) {
-#pragma unroll
-        for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * 18 + kk * 4 + fk];
-#pragma unroll
-        for (int n = 0; n < NC; n++) bf[n] = sB[(((wv & 1) * 64 + 16 * n + fr) & 127) * 18 + kk * 4 + fk];
-      }
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int n = 0; n < NC; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
-    }
-  }
-  double s = 0;
-#pragma unroll
-  for (int m = 0; m < 4; m++)
-#pragma unroll
-    for (int n = 0; n < NC; n++) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
-  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
-}
-
-// staging probe: NCB = column blocks of 16 per wave (4: 64x64 wave tile, 8: 64x128)
-template <int NCB>
-__global__ __launch_bounds__(256, (NCB == 8 ? 1 : 2)) void k_stage_probe(const double *__restrict__ Aop,
-                                                                          const double *__restrict__ Bop, double *out,
-                                                                          int tiles_per_wg, int ntile_rows) {
-  typedef double d4p __attribute__((ext_vector_type(4)));
-  typedef double d2p __attribute__((ext_vector_type(2)));
-  constexpr int BR = 16 * NCB;  // B rows per wave
-  constexpr int LD = 18;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-  double *lds = reinterpret_cast<double *>(smraw);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fk = lane >> 4;
-  double *sA = lds + wv * ((64 + BR) * LD), *sB = sA + 64 * LD;
-  const int lrow = lane >> 3, lc2 = lane & 7;  // 8 lanes cover the 16 doubles of a chunk row
-  constexpr int NLA = 64 / 8, NLB = BR / 8;
-  d4p acc[4][NCB];
-#pragma unroll
-  for (int m = 0; m < 4; m++)
-#pragma unroll
-    for (int n = 0; n < NCB; n++) acc[m][n] = (d4p){0, 0, 0, 0};
-  for (int t = 0; t < tiles_per_wg; t++) {
-    // operand tiles of this step: row-major tiles of 128 x 128 doubles; every workgroup walks its own sequence
-    const int ti = (blockIdx.x * 7 + t * 3) % ntile_rows, tj = (blockIdx.x * 5 + t) % ntile_rows;
-    const double *Ab = Aop + (size_t)ti * NB * NB + (size_t)((wv >> 1) * 64) * NB;
-    const double *Bb = Bop + (size_t)tj * NB * NB + (size_t)(((wv & 1) * BR) % NB) * NB;
-    d2p pa[NLA], pb[NLB];
-#pragma unroll
-    for (int q = 0; q < NLA; q++) pa[q] = *reinterpret_cast<const d2p *>(Ab + (lrow + 8 * q) * NB + 2 * lc2);
-#pragma unroll
-    for (int q = 0; q < NLB; q++) pb[q] = *reinterpret_cast<const d2p *>(Bb + ((lrow + 8 * q) % NB) * NB + 2 * lc2);
-    for (int ch = 0; ch < 16; ch++) {  // K = 256 in chunks of 16
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int q = 0; q < NLA; q++) *reinterpret_cast<d2p *>(sA + (lrow + 8 * q) * LD + 2 * lc2) = pa[q];
-#pragma unroll
-      for (int q = 0; q < NLB; q++) *reinterpret_cast<d2p *>(sB + (lrow + 8 * q) * LD + 2 * lc2) = pb[q];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (ch + 1 < 16) {
-        const int k0 = ((ch + 1) & 7) * 16;
-#pragma unroll
-        for (int q = 0; q < NLA; q++) pa[q] = *reinterpret_cast<const d2p *>(Ab + (lrow + 8 * q) * NB + k0 + 2 * lc2);
-#pragma unroll
-        for (int q = 0; q < NLB; q++) pb[q] = *reinterpret_cast<const d2p *>(Bb + ((lrow + 8 * q) % NB) * NB + k0 + 2 * lc2);
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        double af[4], bf[NCB];
-#pragma unroll
-        for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * LD + kk * 4 + fk];
-#pragma unroll
-        for (int n = 0; n < NCB; n++) bf[n] = sB[(16 * n + fr) * LD + kk * 4 + fk];
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-          for (int n = 0; n < NCB; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
-      }
-    }
-  }
-  double s = 0;  // consume the accumulators one column block at a time (no 256-register reduction)
-#pragma unroll
-  for (int n = 0; n < NCB; n++) {
-    double sn = 0;
-#pragma unroll
-    for (int m = 0; m < 4; m++) sn += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
-    s += sn;
-  }
-  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
-}
-}  // namespace
-
-extern "C" int ba_debug_mfma_probe(int mode, int iters, double *tflops_out) {
-  int dev = 0, ncu = 256;
-  BA_HIP_CHECK(hipGetDevice(&dev));
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  hipEvent_t e0, e1;
-  BA_HIP_CHECK(hipEventCreate(&e0));
-  BA_HIP_CHECK(hipEventCreate(&e1));
-  double *out = nullptr, *Aop = nullptr, *Bop = nullptr;
-  float ms = 0;
-  double flops = 0;
-  if (mode <= 2) {
-    const int per_cu = mode == 2 ? 1 : 2, grid = ncu * per_cu * 4;
-    BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)grid * 256 * sizeof(double)));
-    auto launch = [&]() {
-      switch (mode) {
-        case 0: hipLaunchKernelGGL(k_mfma_probe<0>, dim3(grid), dim3(256), 0, 0, out, iters); break;
-        case 1: hipLaunchKernelGGL(k_mfma_probe<1>, dim3(grid), dim3(256), 0, 0, out, iters); break;
-        default: hipLaunchKernelGGL(k_mfma_probe<2>, dim3(grid), dim3(256), 0, 0, out, iters);
-      }
-    };
-    launch();
-    BA_HIP_CHECK(hipDeviceSynchronize());
-    BA_HIP_CHECK(hipEventRecord(e0, 0));
-    launch();
-    BA_HIP_CHECK(hipEventRecord(e1, 0));
-    BA_HIP_CHECK(hipEventSynchronize(e1));
-    BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    const double nc = mode == 2 ? 8 : 4;
-    flops = (double)grid * 4 /*waves*/ * iters * 4 /*kk*/ * 4 * nc * 2048.0;
-  } else {
-    const int ncb = mode == 3 ? 4 : 8, per_cu = mode == 3 ? 2 : 1, grid = ncu * per_cu, tiles = iters > 0 ? iters : 16;
-    const int ntile_rows = 120;  // 2 x 15.7 MB of operands: cache-resident like the panels of a pair update
-    const size_t lds_bytes = (size_t)4 * (64 + 16 * ncb) * 18 * sizeof(double);
-    BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)grid * 256 * sizeof(double)));
-    BA_HIP_CHECK(hipMalloc((void **)&Aop, (size_t)ntile_rows * NB * NB * sizeof(double)));
-    BA_HIP_CHECK(hipMalloc((void **)&Bop, (size_t)ntile_rows * NB * NB * sizeof(double)));
-    BA_HIP_CHECK(hipMemset(Aop, 0, (size_t)ntile_rows * NB * NB * sizeof(double)));
-    BA_HIP_CHECK(hipMemset(Bop, 0, (size_t)ntile_rows * NB * NB * sizeof(double)));
-    if (mode == 3)
-      BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_probe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    else
-      BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_probe<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    auto launch = [&]() {
-      if (mode == 3) hipLaunchKernelGGL(k_stage_probe<4>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
-      else hipLaunchKernelGGL(k_stage_probe<8>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
-    };
-    launch();
-    BA_HIP_CHECK(hipDeviceSynchronize());
-    BA_HIP_CHECK(hipEventRecord(e0, 0));
-    launch();
-    BA_HIP_CHECK(hipEventRecord(e1, 0));
-    BA_HIP_CHECK(hipEventSynchronize(e1));
-    BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    flops = (double)grid * 4 * tiles * 16 /*chunks*/ * 4 /*kk*/ * 4 * ncb * 2048.0;
-  }
-  *tflops_out = flops / (ms * 1e-3) / 1e12;
-  if (out) (void)hipFree(out);
-  if (Aop) (void)hipFree(Aop);
-  if (Bop) (void)hipFree(Bop);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  return BA_OK;
-}

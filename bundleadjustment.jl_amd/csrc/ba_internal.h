@@ -25,11 +25,17 @@ void ba_set_error(const char *fmt, ...);
   } while (0)
 
 // ---- dense reduced-camera system ------------------------------------------------------------------
-// S is stored as the lower block triangle of NB x NB tiles, tile (i,j), j<=i, at tile index
-// i(i+1)/2 + j, each tile contiguous row-major (128 KiB).  One all-reduce over [0, ntiles*NB*NB)
-// therefore moves exactly the lower triangle.
+// S is stored as the lower block triangle of NB x NB tiles, each tile contiguous row-major (128 KiB).  Tile (i,j),
+// j <= i, sits at tile index col_off[j] + (i - j): a tile column is contiguous (rows j..nt-1).  Tile columns are taken
+// in PAIRS (2q, 2q+1) -- the unit the factorisation works in -- and the pairs are grouped by owner rank q mod world
+// (ascending q inside a group), so that the part of S a rank owns in the distributed factorisation is ONE contiguous
+// range (a single reduce onto its owner per rank).  With world == 1 this is plain column order.
 constexpr int NB = 128;
-__host__ __device__ inline int64_t tile_index(int64_t i, int64_t j) { return i * (i + 1) / 2 + j; }
+__host__ __device__ inline int64_t tix(const int64_t *__restrict__ col_off, int64_t i, int64_t j) {
+  return col_off[j] + (i - j);
+}
+// host: fill col_off (nt entries) and, when own_range != null, the [begin, end) tile ranges of the `world` owners
+void dense_ldl_layout(int64_t nt, int world, std::vector<int64_t> *col_off, std::vector<int64_t> *own_range);
 
 enum ProfClass {
   PC_RESIDUAL = 0,
@@ -65,6 +71,15 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   T *V = nullptr;          // 4 x nt tiles: V_i = L_ik * D_k of two panel pairs (double-buffered for the look-ahead)
   T *Linv = nullptr;       // nt tiles: inverse of each unit-lower diagonal tile
   T *D = nullptr;          // nt*NB pivots (+ nt*NB scratch)
+  int64_t *col_off = nullptr;           // device: tile column offsets (see tix)
+  std::vector<int64_t> h_col_off;       // host copy
+  std::vector<int64_t> own_range;       // world + 1 tile offsets: rank r owns tiles [own_range[r], own_range[r+1])
+  int world = 1, rank = 0;              // distribution of the tile column pairs (owner of pair q: q % world)
+  std::vector<int> h_own_cols;          // tile columns owned by this rank, ascending
+  std::vector<int64_t> h_own_pref;      // h_own_pref[m] = tiles in the owned columns before h_own_cols[m]
+  int *own_cols = nullptr;              // device copies
+  int64_t *own_pref = nullptr;
+  double *flag_sum = nullptr;           // device double: the pivot flag on its way through the all-reduce
   int *flag = nullptr;     // device int: set to 1 on an exactly zero pivot (2: a hoisted diagonal tile never became ready)
   int *ready = nullptr;    // nt device ints: tile (k,k) has received its last trailing update (hoisted-diagonal schedule)
   hipStream_t hoist = nullptr;   // second stream of the hoisted-diagonal schedule (no CU mask)
@@ -75,6 +90,16 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   hipEvent_t ev_chain = nullptr;  // recorded behind each hoisted diagonal kernel
 };
 typedef DenseLDLT<double> DenseLDL;
+
+// transport of the cross-rank sums (ba_comm.hip): RCCL called directly, or a caller-supplied hook
+struct BaComm {
+  int rank = 0, world = 1;
+  ba_comm_fn hook = nullptr;
+  void *hook_ctx = nullptr;
+  void *nccl = nullptr;  // ncclComm_t
+  int64_t calls = 0, bytes = 0;
+  bool active() const { return hook != nullptr || nccl != nullptr; }  // a 1-rank communicator still exercises the path
+};
 
 struct ba_problem {
   int device = 0;
@@ -96,10 +121,7 @@ struct ba_problem {
   struct LMWork *lm = nullptr;
   // communication (multi-GPU)
   int rank = 0, world = 1;
-  double *reduce_buf = nullptr;
-  int64_t reduce_doubles = 0;
-  ba_allreduce_fn allreduce = nullptr;
-  void *allreduce_ctx = nullptr;
+  BaComm comm;
   // profiling
   bool prof_on = false;
   ProfSlot prof[PC_COUNT];
@@ -145,7 +167,7 @@ int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, doubl
 
 // ---- dense LDL^T (ba_dense_ldl.hip) ---------------------------------------------------------------
 template <typename T>
-int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S);
+int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world = 1, int rank = 0);
 template <typename T>
 void dense_ldl_free(DenseLDLT<T> *w);
 int64_t dense_ldl_tiles_doubles(int64_t n_unpadded);  // number of ELEMENTS of the packed lower tiles
@@ -154,9 +176,22 @@ int64_t dense_ldl_tiles_doubles(int64_t n_unpadded);  // number of ELEMENTS of t
 // panel solves; pass forward_done = true to dense_ldl_solve afterwards.
 template <typename T>
 int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b);
+// the same factorisation with the tile column pairs distributed over the ranks of p->comm (owner of pair q: q % world):
+// on entry rank r holds the (summed) tile columns it owns, on exit every rank holds the complete factor (L, Linv, D).
+// No fused forward substitution: call dense_ldl_solve(..., forward_done = false).
+template <typename T>
+int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st);
 // solve S x = b for one right-hand side held in d_b (length nt*NB, overwritten by x)
 template <typename T>
 int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool forward_done);
+
+// ---- transport (ba_comm.hip): all on stream st, in place, no-ops without a communicator --------------------
+int comm_allreduce(ba_problem *p, double *d_buf, int64_t count, hipStream_t st);
+int comm_reduce(ba_problem *p, double *d_buf, int64_t count, int root, hipStream_t st);  // sum lands on root only
+int comm_bcast(ba_problem *p, void *d_buf, int64_t bytes, int root, hipStream_t st);
+int comm_group_begin(ba_problem *p);  // RCCL: fuse the calls up to comm_group_end into one launch
+int comm_group_end(ba_problem *p);
+void comm_free(ba_problem *p);
 
 // ---- LM (ba_lm.hip) ---------------------------------------------------------------------------------
 void lm_free(ba_problem *p);

@@ -118,7 +118,8 @@ int build_tasks(ba_problem *p, SchurTasks *T) {
   return BA_OK;
 }
 
-// [S tiles | rhs(npad) | gc(npad) | hdiag(npad) | SH_COUNT scalars]: gc, hdiag and the first scalars are one all-reduce
+// one device buffer [S tiles | rhs(npad) | gc(npad) | hdiag(npad) | SH_COUNT scalars]: gc, hdiag and the first scalars
+// are one all-reduce
 int64_t reduce_layout(ba_problem *p, int64_t *off_rhs, int64_t *off_gc, int64_t *off_scal) {
   const int64_t n = 9 * p->ncams;
   const int64_t tiles = dense_ldl_tiles_doubles(n);
@@ -185,7 +186,7 @@ static int ensure_xf32(ba_problem *p, LMWorkFull *w) {
 
 static int ensure_f32(LMWorkFull *w) {
   if (w->have32) return BA_OK;
-  BA_CHECK(dense_ldl_alloc<float>(&w->ldl32, w->n, nullptr));
+  BA_CHECK(dense_ldl_alloc<float>(&w->ldl32, w->n, nullptr, w->ldl.world, w->ldl.rank));
   BA_HIP_CHECK(hipMalloc((void **)&w->rhs32, (size_t)w->npad * sizeof(float)));
   w->have32 = true;
   return BA_OK;
@@ -200,19 +201,10 @@ static int lm_ensure(ba_problem *p) {
   w->nequ = 2 * nobs;
   w->n = 9 * ncams;
   w->s.red_doubles = reduce_layout(p, &w->s.off_rhs, &w->s.off_gc, &w->s.off_scal);
-  if (p->reduce_buf) {
-    if (p->reduce_doubles < w->s.red_doubles) {
-      ba_set_error("reduce buffer too small: %lld < %lld doubles", (long long)p->reduce_doubles,
-                   (long long)w->s.red_doubles);
-      return BA_ERR_ARG;
-    }
-    w->s.red = p->reduce_buf;
-    w->s.own_red = false;
-  } else {
-    BA_CHECK(dmalloc(&w->s.red, w->s.red_doubles));
-    w->s.own_red = true;
-  }
-  BA_CHECK(dense_ldl_alloc(&w->ldl, w->n, w->s.red));
+  BA_CHECK(dmalloc(&w->s.red, w->s.red_doubles));
+  w->s.own_red = true;
+  // with a communicator the tile column pairs of S are laid out by owner rank (one contiguous range per rank)
+  BA_CHECK(dense_ldl_alloc(&w->ldl, w->n, w->s.red, p->comm.active() ? p->comm.world : 1, p->comm.active() ? p->comm.rank : 0));
   w->npad = w->ldl.n;
   w->rhs = w->s.red + w->s.off_rhs;
   w->gc = w->s.red + w->s.off_gc;
@@ -272,16 +264,32 @@ void lm_free(ba_problem *p) {
   p->lm = nullptr;
 }
 
-// all-reduce [off, off+count) of the reduce buffer over the ranks (no-op on one GPU)
+// all-reduce [off, off+count) of the reduce buffer over the ranks (no-op without a communicator; a communicator of one
+// rank is still called: lets one GPU exercise the path)
 static int comm_sum(ba_problem *p, LMWorkFull *w, int64_t off, int64_t count, hipStream_t st) {
-  if (!p->allreduce) return BA_OK;  // a hook set at world == 1 is still called (identity): lets one GPU exercise the path
-  ProfScope ps(p, PC_COMM, st);
-  int rc = p->allreduce(p->allreduce_ctx, off, count, (void *)st);
-  if (rc != 0) {
-    ba_set_error("all-reduce hook failed (%d)", rc);
-    return BA_ERR_COMM;
+  return comm_allreduce(p, w->s.red + off, count, st);
+}
+
+// BA_DIST_FACTOR=0: keep the whole reduced camera system on every rank (one all-reduce of S, replicated factorisation)
+static bool dist_factor_on(ba_problem *p) {
+  static const bool off = [] { const char *e = getenv("BA_DIST_FACTOR"); return e && e[0] == '0'; }();
+  return p->comm.active() && !off;
+}
+
+// the partial sums of S held by every rank -> the complete tile columns on their owners (distributed factorisation), or
+// the complete S everywhere (replicated); the right-hand side is needed by every rank either way
+static int reduce_camera_system(ba_problem *p, LMWorkFull *w, hipStream_t st) {
+  if (!p->comm.active()) return BA_OK;
+  if (!dist_factor_on(p)) return comm_sum(p, w, 0, w->s.off_gc, st);  // S tiles and rhs are adjacent
+  BA_CHECK(comm_group_begin(p));
+  int rc = BA_OK;
+  for (int r = 0; r < w->ldl.world && rc == BA_OK; r++) {
+    const int64_t b = w->ldl.own_range[(size_t)r], e = w->ldl.own_range[(size_t)r + 1];
+    rc = comm_reduce(p, w->ldl.S + b * NB * NB, (e - b) * NB * NB, r, st);
   }
-  return BA_OK;
+  BA_CHECK(comm_group_end(p));
+  BA_CHECK(rc);
+  return comm_sum(p, w, w->s.off_rhs, w->npad, st);
 }
 
 // r, J and the normal-equation blocks at w->x; fills sharded/replicated scalars RSQ?, GP, GC, X_P, X_C
@@ -329,14 +337,15 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   // every rank holds partial Hcc / Schur sums; the lambda I of the camera block is added by rank 0 only
   const double lam_diag = (p->rank == 0) ? lambda : 0.0;
   BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, d_lambda));
-  BA_CHECK(launch_schur_blocks(p, &w->tasks, w->J, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->n,
+  BA_CHECK(launch_schur_blocks(p, &w->tasks, w->J, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
                                p->rank == 0 ? w->npad : w->n, st, d_lambda));
   BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
   BA_CHECK(launch_schur_rhs(p, w->J, w->r, w->u, w->rhs, st));
-  BA_CHECK(comm_sum(p, w, 0, w->s.off_gc, st));  // S tiles and rhs are adjacent
+  BA_CHECK(reduce_camera_system(p, w, st));
+  const bool dist = dist_factor_on(p);
   if (normalize != 0) {  // :J / :A column scaling of the camera system from the GLOBAL diagonal (refresh_linearisation)
     BA_CHECK(launch_cam_scale(p, w->hdiag, normalize == 2 ? lambda : 0.0, w->colscale, st, d_lambda));
-    BA_CHECK(launch_scale_S(p, w->n, w->ldl.nt, w->colscale, w->ldl.S, st));
+    BA_CHECK(launch_scale_S(p, w->n, w->ldl.nt, w->colscale, w->ldl.S, w->ldl.col_off, st));
     BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));
   }
   w->last_f32 = facto_f32;
@@ -344,9 +353,17 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
     BA_CHECK(ensure_f32(w));
     BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, dense_ldl_tiles_doubles(w->n), st));
     BA_CHECK(launch_convert(w->rhs, w->rhs32, w->npad, st));
-    BA_CHECK(dense_ldl_factor<float>(p, &w->ldl32, st, nullptr, w->rhs32));
-    BA_CHECK(dense_ldl_solve<float>(p, &w->ldl32, w->rhs32, st, true));
+    if (dist) {
+      BA_CHECK(dense_ldl_factor_dist<float>(p, &w->ldl32, st));
+      BA_CHECK(dense_ldl_solve<float>(p, &w->ldl32, w->rhs32, st, false));
+    } else {
+      BA_CHECK(dense_ldl_factor<float>(p, &w->ldl32, st, nullptr, w->rhs32));
+      BA_CHECK(dense_ldl_solve<float>(p, &w->ldl32, w->rhs32, st, true));
+    }
     BA_CHECK(launch_convert(w->rhs32, w->rhs, w->npad, st));
+  } else if (dist) {
+    BA_CHECK(dense_ldl_factor_dist(p, &w->ldl, st));
+    BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st, false));
   } else {
     BA_CHECK(dense_ldl_factor(p, &w->ldl, st, nullptr, w->rhs));  // forward substitution of rhs rides along
     BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st, true));
@@ -397,7 +414,7 @@ static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 
 // ---- recorded launch sequences ------------------------------------------------------------------------------------------
 static bool graphs_allowed(ba_problem *p, LMWorkFull *w) {
-  if (w->g_off || p->prof_on || p->allreduce) return false;  // per-kernel events / host hook
+  if (w->g_off || p->prof_on || p->comm.active()) return false;  // per-kernel events / communicator
   // the hoisted-diagonal schedule of large factorisations has a kernel wait for a flag raised by a kernel running
   // beside it: only with real streams is that concurrency certain (and the graphs gain nothing at that size)
   if (w->ldl.nt >= 34) return false;  // = HOIST_MIN_TILES + 2 of dense_ldl_factor (above its HOIST_MAX_TILES graphs gain nothing either)
@@ -503,32 +520,6 @@ static int accept_refresh(ba_problem *p, LMWorkFull *w, bool xf32, hipStream_t s
   }
   BA_HIP_CHECK(hipGraphLaunch(g, st));
   BA_HIP_CHECK(hipStreamSynchronize(st));
-  return BA_OK;
-}
-
-extern "C" int ba_lm_reduce_doubles(ba_problem *p, int64_t *count) {
-  if (!p || !count) return BA_ERR_ARG;
-  *count = reduce_layout(p, nullptr, nullptr, nullptr);
-  return BA_OK;
-}
-
-extern "C" int ba_lm_set_comm(ba_problem *p, int rank, int world, double *d_reduce_buf, int64_t buf_doubles,
-                              ba_allreduce_fn fn, void *ctx) {
-  if (!p || world < 1 || rank < 0 || rank >= world) return BA_ERR_ARG;
-  if (p->lm) {
-    ba_set_error("ba_lm_set_comm must be called before the first solve on this handle");
-    return BA_ERR_ARG;
-  }
-  if (world > 1 && (!fn || !d_reduce_buf)) {
-    ba_set_error("ba_lm_set_comm: world > 1 needs a reduce buffer and an all-reduce hook");
-    return BA_ERR_ARG;
-  }
-  p->rank = rank;
-  p->world = world;
-  p->reduce_buf = d_reduce_buf;
-  p->reduce_doubles = buf_doubles;
-  p->allreduce = fn;
-  p->allreduce_ctx = ctx;
   return BA_OK;
 }
 

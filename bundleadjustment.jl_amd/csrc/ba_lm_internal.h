@@ -37,8 +37,8 @@ struct LMWork {
 int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const double *d_gp, double *d_Uinv,
                       double *d_u, hipStream_t st, const double *d_lambda = nullptr);
 int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
-                        const double *d_Hcc, double lambda, double *d_S, int64_t n, int64_t npad, hipStream_t st,
-                        const double *d_lambda = nullptr);
+                        const double *d_Hcc, double lambda, double *d_S, const int64_t *d_col_off, int64_t n, int64_t npad,
+                        hipStream_t st, const double *d_lambda = nullptr);
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
                      hipStream_t st);
 int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,
@@ -51,6 +51,7 @@ int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, 
 int launch_hcc_diag(ba_problem *p, const double *d_Hcc, double *d_hdiag, hipStream_t st);
 int launch_cam_scale(ba_problem *p, const double *d_hdiag, double add, double *d_dsc, hipStream_t st,
                      const double *d_lambda = nullptr);
-int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, double *d_S, hipStream_t st);
+int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, double *d_S, const int64_t *d_col_off,
+                   hipStream_t st);
 int launch_scale_scalar(ba_problem *p, int64_t n, double *d_v, double alpha, hipStream_t st);
 int launch_scale_vec(ba_problem *p, int64_t n, const double *d_s, double *d_v, int divide, hipStream_t st);

@@ -155,9 +155,9 @@ __global__ __launch_bounds__(BLK) void k_schur_prep(int64_t npnts, double lambda
 // Per task the wave loads J_a (24), J_b (24) and U_p^-1 (6) with one coalesced instruction into its LDS slot,
 // lane l then owns elements l and 64+l (< 81) of the 9x9 block.  Only elements with global row >= col are written
 // (lower triangle, packed NB x NB tiles).
-__device__ inline void s_store(double *S, int64_t gr, int64_t gc, double v) {
+__device__ inline void s_store(double *S, const int64_t *__restrict__ co, int64_t gr, int64_t gc, double v) {
   int64_t ti = gr / NB, tj = gc / NB;
-  S[(tile_index(ti, tj) * NB + (gr - ti * NB)) * NB + (gc - tj * NB)] = v;
+  S[(tix(co, ti, tj) * NB + (gr - ti * NB)) * NB + (gc - tj * NB)] = v;
 }
 
 // Y_b = U_p^-1 A_b'  (3x2, row-major) per observation: the point-side half of Q_ab = A_a Y_b
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
                                                        const int *__restrict__ task_a, const int *__restrict__ task_b,
                                                        const double *__restrict__ J, const double *__restrict__ Y,
                                                        const double *__restrict__ Hcc, double lambda,
-                                                       const double *__restrict__ lam_dev, double *__restrict__ S) {
+                                                       const double *__restrict__ lam_dev, double *__restrict__ S,
+                                                       const int64_t *__restrict__ co) {
   __shared__ double stage[BLK / 64][2][48];
   if (lam_dev) lambda *= lam_dev[0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
           int hi = i > j ? i : j, lo = i > j ? j : i;
           v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i == j ? lambda : 0.0);
         }
-        if (r0 + i >= c0 + j) s_store(S, r0 + i, c0 + j, v);
+        if (r0 + i >= c0 + j) s_store(S, co, r0 + i, c0 + j, v);
       }
     }
   }
@@ -286,13 +287,14 @@ __global__ __launch_bounds__(BLK) void k_hcc_diag(int64_t ncams, const double *_
 }
 
 // one workgroup per stored tile: S_ij /= d_i d_j   (padding rows/columns have d = 1)
-__global__ __launch_bounds__(BLK) void k_scale_S(int64_t n, int64_t nt, const double *__restrict__ dsc, double *__restrict__ S) {
-  const int64_t t = blockIdx.x;
+__global__ __launch_bounds__(BLK) void k_scale_S(int64_t n, int64_t nt, const double *__restrict__ dsc, double *__restrict__ S,
+                                                  const int64_t *__restrict__ co) {
+  const int64_t t = blockIdx.x;  // enumerates the lower tile pairs (ti >= tj) row by row; the storage order is co's
   int64_t ti = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
   while (ti * (ti + 1) / 2 > t) ti--;
   const int64_t tj = t - ti * (ti + 1) / 2;
-  double *T = S + t * NB * NB;
+  double *T = S + tix(co, ti, tj) * NB * NB;
   for (int e = threadIdx.x; e < NB * NB; e += BLK) {
     const int64_t r = ti * NB + (e >> 7), c = tj * NB + (e & (NB - 1));
     const double dr = r < n ? dsc[r] : 1.0, dc = c < n ? dsc[c] : 1.0;
@@ -301,9 +303,9 @@ __global__ __launch_bounds__(BLK) void k_scale_S(int64_t n, int64_t nt, const do
 }
 
 // unit diagonal on the padding rows n..npad-1 so that the padded matrix stays factorisable
-__global__ void k_pad_diag(int64_t n, int64_t npad, double *S) {
+__global__ void k_pad_diag(int64_t n, int64_t npad, double *S, const int64_t *co) {
   int64_t i = n + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < npad) s_store(S, i, i, 1.0);
+  if (i < npad) s_store(S, co, i, i, 1.0);
 }
 
 // ---- back-substitution of the points: dp = -(u_p + U^-1 sum_a A_a' (B_a dc[c_a])) ----------------------------------
@@ -445,8 +447,8 @@ int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const d
 }
 
 int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
-                        const double *d_Hcc, double lambda, double *d_S, int64_t n, int64_t npad, hipStream_t st,
-                        const double *d_lambda) {
+                        const double *d_Hcc, double lambda, double *d_S, const int64_t *d_col_off, int64_t n, int64_t npad,
+                        hipStream_t st, const double *d_lambda) {
   ProfScope ps(p, PC_SCHUR_S, st);
   BA_HIP_CHECK(hipMemsetAsync(d_S, 0, (size_t)dense_ldl_tiles_doubles(n) * sizeof(double), st));
   if (p->nobs > 0)
@@ -455,9 +457,9 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
     int64_t nb = (T->nkeys + BLK / 64 - 1) / (BLK / 64);
     if (nb > (int64_t)1 << 22) nb = (int64_t)1 << 22;  // 2^22 blocks x 256 lanes = 2^30 work-items
     hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nb), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
-                       T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, d_S);
+                       T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, d_S, d_col_off);
   }
-  if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S);
+  if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S, d_col_off);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
@@ -478,8 +480,9 @@ int launch_cam_scale(ba_problem *p, const double *d_hdiag, double add, double *d
   return BA_OK;
 }
 
-int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, double *d_S, hipStream_t st) {
-  hipLaunchKernelGGL(k_scale_S, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(BLK), 0, st, n, nt, d_dsc, d_S);
+int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, double *d_S, const int64_t *d_col_off,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(k_scale_S, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(BLK), 0, st, n, nt, d_dsc, d_S, d_col_off);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }

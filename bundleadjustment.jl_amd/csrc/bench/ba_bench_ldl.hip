@@ -1,0 +1,294 @@
+// Bench-only entry points of the dense LDL' kernels (tools/bench_update.py, bench_diag.py, bench_mfma_probe.py): built into
+// tools/libba_bench.so, NOT into libba_hip.so.  This translation unit includes the product source so that the probes
+// time the very kernels that ship.
+#include "../ba_dense_ldl.hip"
+
+static int set_bench_kernel_attrs() {
+  typedef double T;
+  BA_CHECK(set_kernel_attrs<T>());
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 9>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
+  return BA_OK;
+}
+
+// micro-benchmark of the bulk trailing update (tools/bench_update.py): one pair update of an nt x nt tile matrix
+extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_out) {
+  BA_CHECK(set_bench_kernel_attrs());
+  const size_t tiles = (size_t)nt * (nt + 1) / 2 * NB * NB;
+  double *S = nullptr, *V = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&S, tiles * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&V, (size_t)2 * nt * NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMemset(S, 0, tiles * sizeof(double)));
+  BA_HIP_CHECK(hipMemset(V, 0, (size_t)2 * nt * NB * NB * sizeof(double)));
+  const int m = nt - 2, nblk = m * (m + 1) / 2, grid = ((nblk + 7) / 8) * 8;
+  std::vector<int64_t> h_co;
+  dense_ldl_layout(nt, 1, &h_co, nullptr);
+  int64_t *co = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&co, (size_t)nt * sizeof(int64_t)));
+  BA_HIP_CHECK(hipMemcpy(co, h_co.data(), (size_t)nt * sizeof(int64_t), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  BA_HIP_CHECK(hipEventCreate(&e0));
+  BA_HIP_CHECK(hipEventCreate(&e1));
+  auto launch = [&]() {
+    const double *V0 = V, *V1 = V + (size_t)nt * NB * NB;
+    switch (variant) {
+      case 1: hipLaunchKernelGGL((k_ldl_update<double, 1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 2: hipLaunchKernelGGL((k_ldl_update<double, 1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 8: hipLaunchKernelGGL((k_ldl_update<double, 1, 8>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 9: hipLaunchKernelGGL((k_ldl_update<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      default: hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr);
+    }
+  };
+  {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_ldl_update<double, 1, 0>), 256, GEMM_LDS_ELEMS * sizeof(double));
+    if (variant == 0) fprintf(stderr, "[debug] update<1>: occupancy API says %d workgroups/CU at %zu B LDS\n", nb, GEMM_PRIV_LDS_ELEMS * sizeof(double));
+  }
+  launch();
+  BA_HIP_CHECK(hipDeviceSynchronize());
+  BA_HIP_CHECK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; r++) launch();
+  BA_HIP_CHECK(hipEventRecord(e1, 0));
+  BA_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / reps;
+  (void)hipFree(S);
+  (void)hipFree(V);
+  (void)hipFree(co);
+  return BA_OK;
+}
+
+// diagnostic: phase cycle counts of the diagonal-tile kernel (load, pivots, inverse16, trsm16+syrk16, full inverse, store)
+extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
+  BA_CHECK(set_bench_kernel_attrs());
+  double *S = nullptr, *Li = nullptr, *D = nullptr;
+  int *flag = nullptr;
+  unsigned long long *st = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&S, NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&Li, NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMemset(Li, 0, NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&D, NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&flag, sizeof(int)));
+  BA_HIP_CHECK(hipMalloc((void **)&st, 6 * sizeof(unsigned long long)));
+  std::vector<double> h((size_t)NB * NB, 0.0);
+  for (int i = 0; i < NB; i++)
+    for (int j = 0; j <= i; j++) h[(size_t)i * NB + j] = (i == j) ? 300.0 + i : 1.0 / (1 + i + j);
+  hipEvent_t e0, e1;
+  BA_HIP_CHECK(hipEventCreate(&e0));
+  BA_HIP_CHECK(hipEventCreate(&e1));
+  float ms = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    BA_HIP_CHECK(hipMemcpy(S, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    BA_HIP_CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(double), 0, S, Li, D, flag, rep == 2 ? st : nullptr, (const int *)nullptr);
+    BA_HIP_CHECK(hipEventRecord(e1, 0));
+    BA_HIP_CHECK(hipEventSynchronize(e1));
+    if (rep == 1) BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  unsigned long long hs[6];
+  BA_HIP_CHECK(hipMemcpy(hs, st, sizeof hs, hipMemcpyDeviceToHost));
+  for (int q = 0; q < 6; q++) cycles6[q] = (double)hs[q];
+  *ms_out = ms;
+  (void)hipFree(S); (void)hipFree(Li); (void)hipFree(D); (void)hipFree(flag); (void)hipFree(st);
+  return BA_OK;
+}
+
+// ---- MFMA ceiling probes (tools/bench_mfma_probe.py): how close a K loop of the update kernel's shape can get to the
+// f64 matrix peak.  MODE 0: MFMAs only, 4x4 accumulator blocks per wave, 2 waves per SIMD; MODE 1: the same with the
+// update kernel's LDS operand reads (8 ds_read_b64 per 16 MFMAs), no staging; MODE 2: 4x8 blocks per wave, one wave per
+// SIMD, no staging.  Modes 3 / 4 (k_stage_probe): the full wave-private staging loop (global -> registers -> LDS, chunks
+// of 16, next chunk's loads in flight during the MFMAs) on operands in global memory, K = 256 per "tile", 16 tiles per
+// persistent workgroup, no C tile traffic: 3 = the shipped geometry (64x64 per wave, 2 workgroups per CU), 4 = 64x128
+// per wave, 1 workgroup per CU.
+// Measured (TFLOP/s): 0: 78.0   1: 78.0   2: 58.6 (compiler spills)   3: 67.7-69.8   4: 64.3-65.1.
+// (Also tried in this probe: two LDS buffers of 8-wide chunks per wave at the same 73.7 KB, row stride 9 doubles: 43 --
+// the 72-byte rows break the 16-byte LDS writes.)
+// With them: the shipped kernel's 59.8 in tools/bench_update.py becomes 64-65 with a store-only epilogue (variant 1), and
+// reading the C tile costs the same 6-7 TFLOP/s wherever the loads are placed (end of tile, or start of tile into the
+// accumulators, with or without persistent workgroups): the pair update moves 2 x 0.98 GB of C per launch for 0.063
+// TFLOP, i.e. at K = 256 the trailing matrix's HBM traffic is a third of the kernel's time when it is not overlapped.
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void k_mfma_probe(double *out, int iters) {
+  typedef double d4p __attribute__((ext_vector_type(4)));
+  constexpr int NC = (MODE == 2) ? 8 : 4;
+  __shared__ double sm[(64 + 128) * 18];
+  for (int i = threadIdx.x; i < (64 + 128) * 18; i += 256) sm[i] = 1.0 + 1e-9 * i;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fk = lane >> 4;
+  d4p acc[4][NC];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < NC; n++) acc[m][n] = (d4p){0, 0, 0, 0};
+  double af[4], bf[NC];
+#pragma unroll
+  for (int m = 0; m < 4; m++) af[m] = 1.0 + lane * 1e-3 + m;
+#pragma unroll
+  for (int n = 0; n < NC; n++) bf[n] = 2.0 - lane * 1e-3 + n;
+  const double *sA = sm, *sB = sm + 64 * 18;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      if (MODE >= 1) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * 18 + kk * 4 + fk];
+#pragma unroll
+        for (int n = 0; n < NC; n++) bf[n] = sB[(((wv & 1) * 64 + 16 * n + fr) & 127) * 18 + kk * 4 + fk];
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < NC; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+  }
+  double s = 0;
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < NC; n++) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// staging probe: NCB = column blocks of 16 per wave (4: 64x64 wave tile, 8: 64x128)
+template <int NCB>
+__global__ __launch_bounds__(256, (NCB == 8 ? 1 : 2)) void k_stage_probe(const double *__restrict__ Aop,
+                                                                          const double *__restrict__ Bop, double *out,
+                                                                          int tiles_per_wg, int ntile_rows) {
+  typedef double d4p __attribute__((ext_vector_type(4)));
+  typedef double d2p __attribute__((ext_vector_type(2)));
+  constexpr int BR = 16 * NCB;  // B rows per wave
+  constexpr int LD = 18;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  double *lds = reinterpret_cast<double *>(smraw);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fk = lane >> 4;
+  double *sA = lds + wv * ((64 + BR) * LD), *sB = sA + 64 * LD;
+  const int lrow = lane >> 3, lc2 = lane & 7;  // 8 lanes cover the 16 doubles of a chunk row
+  constexpr int NLA = 64 / 8, NLB = BR / 8;
+  d4p acc[4][NCB];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < NCB; n++) acc[m][n] = (d4p){0, 0, 0, 0};
+  for (int t = 0; t < tiles_per_wg; t++) {
+    // operand tiles of this step: row-major tiles of 128 x 128 doubles; every workgroup walks its own sequence
+    const int ti = (blockIdx.x * 7 + t * 3) % ntile_rows, tj = (blockIdx.x * 5 + t) % ntile_rows;
+    const double *Ab = Aop + (size_t)ti * NB * NB + (size_t)((wv >> 1) * 64) * NB;
+    const double *Bb = Bop + (size_t)tj * NB * NB + (size_t)(((wv & 1) * BR) % NB) * NB;
+    d2p pa[NLA], pb[NLB];
+#pragma unroll
+    for (int q = 0; q < NLA; q++) pa[q] = *reinterpret_cast<const d2p *>(Ab + (lrow + 8 * q) * NB + 2 * lc2);
+#pragma unroll
+    for (int q = 0; q < NLB; q++) pb[q] = *reinterpret_cast<const d2p *>(Bb + ((lrow + 8 * q) % NB) * NB + 2 * lc2);
+    for (int ch = 0; ch < 16; ch++) {  // K = 256 in chunks of 16
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < NLA; q++) *reinterpret_cast<d2p *>(sA + (lrow + 8 * q) * LD + 2 * lc2) = pa[q];
+#pragma unroll
+      for (int q = 0; q < NLB; q++) *reinterpret_cast<d2p *>(sB + (lrow + 8 * q) * LD + 2 * lc2) = pb[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (ch + 1 < 16) {
+        const int k0 = ((ch + 1) & 7) * 16;
+#pragma unroll
+        for (int q = 0; q < NLA; q++) pa[q] = *reinterpret_cast<const d2p *>(Ab + (lrow + 8 * q) * NB + k0 + 2 * lc2);
+#pragma unroll
+        for (int q = 0; q < NLB; q++) pb[q] = *reinterpret_cast<const d2p *>(Bb + ((lrow + 8 * q) % NB) * NB + k0 + 2 * lc2);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        double af[4], bf[NCB];
+#pragma unroll
+        for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * LD + kk * 4 + fk];
+#pragma unroll
+        for (int n = 0; n < NCB; n++) bf[n] = sB[(16 * n + fr) * LD + kk * 4 + fk];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int n = 0; n < NCB; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  double s = 0;  // consume the accumulators one column block at a time (no 256-register reduction)
+#pragma unroll
+  for (int n = 0; n < NCB; n++) {
+    double sn = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) sn += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    s += sn;
+  }
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int ba_debug_mfma_probe(int mode, int iters, double *tflops_out) {
+  int dev = 0, ncu = 256;
+  BA_HIP_CHECK(hipGetDevice(&dev));
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  hipEvent_t e0, e1;
+  BA_HIP_CHECK(hipEventCreate(&e0));
+  BA_HIP_CHECK(hipEventCreate(&e1));
+  double *out = nullptr, *Aop = nullptr, *Bop = nullptr;
+  float ms = 0;
+  double flops = 0;
+  if (mode <= 2) {
+    const int per_cu = mode == 2 ? 1 : 2, grid = ncu * per_cu * 4;
+    BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)grid * 256 * sizeof(double)));
+    auto launch = [&]() {
+      switch (mode) {
+        case 0: hipLaunchKernelGGL(k_mfma_probe<0>, dim3(grid), dim3(256), 0, 0, out, iters); break;
+        case 1: hipLaunchKernelGGL(k_mfma_probe<1>, dim3(grid), dim3(256), 0, 0, out, iters); break;
+        default: hipLaunchKernelGGL(k_mfma_probe<2>, dim3(grid), dim3(256), 0, 0, out, iters);
+      }
+    };
+    launch();
+    BA_HIP_CHECK(hipDeviceSynchronize());
+    BA_HIP_CHECK(hipEventRecord(e0, 0));
+    launch();
+    BA_HIP_CHECK(hipEventRecord(e1, 0));
+    BA_HIP_CHECK(hipEventSynchronize(e1));
+    BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double nc = mode == 2 ? 8 : 4;
+    flops = (double)grid * 4 /*waves*/ * iters * 4 /*kk*/ * 4 * nc * 2048.0;
+  } else {
+    const int ncb = mode == 3 ? 4 : 8, per_cu = mode == 3 ? 2 : 1, grid = ncu * per_cu, tiles = iters > 0 ? iters : 16;
+    const int ntile_rows = 120;  // 2 x 15.7 MB of operands: cache-resident like the panels of a pair update
+    const size_t lds_bytes = (size_t)4 * (64 + 16 * ncb) * 18 * sizeof(double);
+    BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)grid * 256 * sizeof(double)));
+    BA_HIP_CHECK(hipMalloc((void **)&Aop, (size_t)ntile_rows * NB * NB * sizeof(double)));
+    BA_HIP_CHECK(hipMalloc((void **)&Bop, (size_t)ntile_rows * NB * NB * sizeof(double)));
+    BA_HIP_CHECK(hipMemset(Aop, 0, (size_t)ntile_rows * NB * NB * sizeof(double)));
+    BA_HIP_CHECK(hipMemset(Bop, 0, (size_t)ntile_rows * NB * NB * sizeof(double)));
+    if (mode == 3)
+      BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_probe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    else
+      BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_probe<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    auto launch = [&]() {
+      if (mode == 3) hipLaunchKernelGGL(k_stage_probe<4>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
+      else hipLaunchKernelGGL(k_stage_probe<8>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
+    };
+    launch();
+    BA_HIP_CHECK(hipDeviceSynchronize());
+    BA_HIP_CHECK(hipEventRecord(e0, 0));
+    launch();
+    BA_HIP_CHECK(hipEventRecord(e1, 0));
+    BA_HIP_CHECK(hipEventSynchronize(e1));
+    BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    flops = (double)grid * 4 * tiles * 16 /*chunks*/ * 4 /*kk*/ * 4 * ncb * 2048.0;
+  }
+  *tflops_out = flops / (ms * 1e-3) / 1e12;
+  if (out) (void)hipFree(out);
+  if (Aop) (void)hipFree(Aop);
+  if (Bop) (void)hipFree(Bop);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return BA_OK;
+}

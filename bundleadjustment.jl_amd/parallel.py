@@ -63,56 +63,92 @@ def gather_solution(x_local, info, ncams, group=None):
 
 
 class CameraBlockReducer:
-    """Owns the reduce buffer of one shard (a torch tensor, so that torch.distributed can address it) and the
-    all-reduce hook the C library calls (ba_lm_set_comm).  The hook sums buf[offset : offset+count] over the ranks in
-    place.  With the NCCL (= RCCL) backend the collective is enqueued on the stream the library passes in; with gloo
-    (CPU tests, or several ranks sharing one GPU) the range is staged through pinned host memory."""
+    """Attaches the cross-rank transport of one shard's handle (include/ba_hip.h, "multi-GPU"): the camera-side sums
+    (J'r camera part, diag(J'J), right-hand side, scalars: all-reduce), the reduce of each rank's part of the reduced
+    camera matrix onto its owner, and the broadcast of the factored panels.
+
+    * torch.distributed backend "nccl" (= RCCL over xGMI on MI355X): rank 0 draws the RCCL unique id from the library,
+      torch.distributed only carries those 128 bytes to the other ranks; the library then opens its OWN RCCL communicator
+      (ba_lm_set_comm_rccl) and issues every collective itself, from C, on its stream.  No Python in the LM loop.
+    * backend "gloo" (the CPU-side tests; several ranks sharing one GPU, where RCCL cannot run): the hook transport
+      (ba_lm_set_comm_hook) -- each operation is staged through host memory and carried by gloo."""
 
     def __init__(self, nlp, group=None):
         import torch
         import torch.distributed as dist
         from . import _lib
-        self.torch, self.dist, self.group = torch, dist, group
+        self._lib, self.nlp = _lib, nlp
+        self.dist, self.group = dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        n = C.c_int64(0)
-        _lib.check(_lib.lib().ba_lm_reduce_doubles(nlp.handle, C.byref(n)))
-        self.buf = torch.zeros(n.value, dtype=torch.float64, device=f"cuda:{nlp.device}")
-        self.calls = 0
-        self.bytes = 0
-        self._host = None
+        L = _lib.lib()
+        if self.backend == "nccl":
+            ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+            if self.rank == 0:
+                buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+                _lib.check(L.ba_comm_get_unique_id(buf))
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            ident = ident.to(f"cuda:{nlp.device}")
+            dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            raw = bytes(ident.cpu().tolist())
+            self._id = (C.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(raw)
+            _lib.check(L.ba_lm_set_comm_rccl(nlp.handle, self.rank, self.world, self._id))
+            self._cb = None
+            return
 
-        def _hook(ctx, offset, count, stream):
+        h = nlp.handle
+
+        def _hook(ctx, op, d_buf, count, root, stream):
             try:
-                view = self.buf[offset: offset + count]
-                ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
-                if self.backend == "nccl":
-                    with torch.cuda.stream(ext):
-                        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                nbytes = count if op == _lib.COMM_BCAST_BYTES else 8 * count
+                host = np.empty(nbytes, dtype=np.uint8)
+                _lib.check(L.ba_memcpy_d2h(h, _lib.ptr(host), C.c_void_p(d_buf), nbytes))  # drains the handle's stream first
+                t = torch.from_numpy(host if op == _lib.COMM_BCAST_BYTES else host.view(np.float64))
+                src = (lambda r: dist.get_global_rank(group, r) if group is not None else r)
+                if op == _lib.COMM_ALLREDUCE_F64:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                elif op == _lib.COMM_REDUCE_F64:
+                    dist.reduce(t, dst=src(root), op=dist.ReduceOp.SUM, group=group)
+                    if self.rank != root:
+                        return 0  # only the root's buffer receives the sum
+                elif op == _lib.COMM_BCAST_BYTES:
+                    dist.broadcast(t, src=src(root), group=group)
+                    if self.rank == root:
+                        return 0
                 else:
-                    # host staging, fully synchronous, on torch's own stream (torch's pinned-memory allocator must not
-                    # record events on the library's stream: that stream dies with the handle)
-                    ext.synchronize()
-                    if self._host is None or self._host.numel() < count:
-                        self._host = torch.empty(max(count, 1 << 16), dtype=torch.float64).pin_memory()
-                    h = self._host[:count]
-                    h.copy_(view)
-                    torch.cuda.current_stream().synchronize()
-                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-                    view.copy_(h)
-                    torch.cuda.current_stream().synchronize()
-                self.calls += 1
-                self.bytes += 8 * count
+                    return 2
+                _lib.check(L.ba_memcpy_h2d(h, C.c_void_p(d_buf), _lib.ptr(host), nbytes))
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
                 import sys
-                print(f"[ba] all-reduce hook failed: {e!r}", file=sys.stderr)
+                print(f"[ba] communication hook failed: {e!r}", file=sys.stderr)
                 return 1
 
-        self._cb = _lib.ALLREDUCE_CB(_hook)  # keep alive
-        _lib.check(_lib.lib().ba_lm_set_comm(nlp.handle, self.rank, self.world, C.c_void_p(self.buf.data_ptr()),
-                                             n.value, self._cb, None))
+        self._cb = _lib.COMM_CB(_hook)  # keep alive as long as the handle may call it
+        _lib.check(L.ba_lm_set_comm_hook(nlp.handle, self.rank, self.world, self._cb, None))
+
+    def _stats(self):
+        calls, nbytes = C.c_int64(0), C.c_int64(0)
+        self._lib.check(self._lib.lib().ba_comm_stats(self.nlp.handle, C.byref(calls), C.byref(nbytes)))
+        return calls.value, nbytes.value
+
+    @property
+    def calls(self):
+        return self._stats()[0]
+
+    @property
+    def bytes(self):
+        return self._stats()[1]
+
+
+def dist_layout(nt, world):
+    """(col_off, own_range) of the reduced camera matrix over `world` ranks (ba_dist_layout)."""
+    from . import _lib
+    col_off = np.zeros(nt, dtype=np.int64)
+    own = np.zeros(world + 1, dtype=np.int64)
+    _lib.check(_lib.lib().ba_dist_layout(nt, world, _lib.ptr(col_off), _lib.ptr(own)))
+    return col_off, own
 
 
 def allreduce_sum_numpy(a, group=None):

@@ -33,7 +33,7 @@ enum {
   BA_ERR_IO = 3,        /* BAL file missing / malformed / bzip2 runtime missing */
   BA_ERR_ZERO_PIVOT = 4,/* LDL^T met an exactly zero pivot: SQDException, src/ldl_aux.jl:45-47,199 */
   BA_ERR_NAN_STEP = 5,  /* |delta| is NaN: status :exception, src/lm.jl:297-302 */
-  BA_ERR_COMM = 6       /* the caller's all-reduce hook failed */
+  BA_ERR_COMM = 6       /* RCCL or the caller's communication hook failed */
 };
 
 /* status of a Levenberg-Marquardt run: src/lm.jl:391-405, src/LevenbergMarquardt.jl:370-380 */
@@ -154,14 +154,32 @@ int ba_lm_solve(ba_problem *p, const ba_lm_opts *opts, double *x_inout, ba_lm_st
                 void *cb_ctx);
 
 /* ---- multi-GPU: observations sharded by point, cameras replicated --------------------------------
- * The only cross-rank data of an iteration are camera-side sums.  The library keeps them in ONE
- * caller-provided device buffer (so the caller's communication library owns the memory) and calls
- * the hook to sum a sub-range of it over all ranks in place, on `stream`.  With no hook the run is
- * single-GPU.  ba_lm_reduce_doubles() gives the buffer length for this shard's camera count. */
-typedef int (*ba_allreduce_fn)(void *ctx, int64_t offset_doubles, int64_t count_doubles, void *stream);
-int ba_lm_reduce_doubles(ba_problem *p, int64_t *count);
-int ba_lm_set_comm(ba_problem *p, int rank, int world, double *d_reduce_buf, int64_t buf_doubles,
-                   ba_allreduce_fn fn, void *ctx);
+ * One process per GPU.  Every rank creates its own shard (ba_problem_create: local observations and points, ALL
+ * cameras) and attaches a communicator BEFORE its first solve.  Per LM iteration the ranks then exchange camera-side
+ * data only: short Float64 all-reduces (J'r camera part, diag(J'J), right-hand side, scalars), one reduce per rank of
+ * the part of the reduced camera matrix that rank owns, and the broadcast of each factored panel pair from its owner
+ * (the dense factorisation is distributed over the tile-column pairs, owner of pair q = q mod world; the triangular
+ * solves are replicated).  The reference is single-process: none of this has a counterpart there.
+ *   ba_lm_set_comm_rccl : RCCL over xGMI, called directly from the library on its own stream.  Rank 0 obtains the
+ *                         128-byte id with ba_comm_get_unique_id and hands it to the other ranks by any means the host
+ *                         has (torch.distributed, MPI.jl, a file); the call is collective (ncclCommInitRank).
+ *   ba_lm_set_comm_hook : the host carries the data.  op: BA_COMM_ALLREDUCE_F64 (count doubles, sum, in place),
+ *                         BA_COMM_REDUCE_F64 (count doubles, the sum lands on `root` only, in place),
+ *                         BA_COMM_BCAST_BYTES (count bytes from `root`).  d_buf is a device pointer; the operation must
+ *                         be ordered after prior work on `stream` and complete (or stream-ordered) on return. */
+enum { BA_COMM_ALLREDUCE_F64 = 0, BA_COMM_REDUCE_F64 = 1, BA_COMM_BCAST_BYTES = 2 };
+#define BA_COMM_ID_BYTES 128
+typedef int (*ba_comm_fn)(void *ctx, int op, void *d_buf, int64_t count, int root, void *stream);
+int ba_comm_get_unique_id(void *id_out /* BA_COMM_ID_BYTES */);
+int ba_lm_set_comm_rccl(ba_problem *p, int rank, int world, const void *id /* BA_COMM_ID_BYTES */);
+int ba_lm_set_comm_hook(ba_problem *p, int rank, int world, ba_comm_fn fn, void *ctx);
+/* Layout of the reduced camera matrix S (lower triangle of 128 x 128 tiles, nt = ceil(9 ncams / 128) tile rows) over
+ * `world` ranks: tile (i, j), j <= i, sits at tile offset col_off[j] + (i - j); the tile columns are taken in pairs
+ * (2q, 2q+1) owned by rank q % world, and rank r's columns fill the contiguous tile range [own_range[r], own_range[r+1]).
+ * col_off: nt entries, own_range: world + 1 entries (may be NULL).  Host-only, needs no device. */
+int ba_dist_layout(int64_t nt, int world, int64_t *col_off, int64_t *own_range);
+/* number of transport calls / bytes handed to the transport since the communicator was attached */
+int ba_comm_stats(ba_problem *p, int64_t *calls, int64_t *bytes);
 
 /* ---- single linear step, exposed for parity tests and profiling ------------------------------------
  * From (x, lambda): delta (nvar) solving (J'J + lambda I) delta = -J' r, and pred2 = 1/2 |J delta + r|^2

@@ -12,6 +12,30 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     ba = ge.load_package()
+    out = dict(rank=rank, world=world)
+    # (a) the distributed factorisation on a system with several tile column pairs (70 cameras: n = 630, 5 tile rows,
+    # pairs owned 0,1,0 / 0,1,2): one LM step of the shards against the step of the unsharded problem
+    big = ba.synthetic.make_problem(70, 500, 2400, seed=8)
+    barr = ba.synthetic.as_arrays(big)
+    bl, binfo = ba.parallel.shard_problem(barr, rank, world)
+    bn = ba.BALNLPModel(arrays=bl, device=0)
+    bred = ba.parallel.CameraBlockReducer(bn)
+    steps = {}
+    for tag, ft in (("f64", None), ("f32", np.float32)):
+        d, half, jtr = ba.lm_step(bn, bl[3], 25.0, facto_type=ft)
+        steps[tag] = (ba.parallel.gather_solution(d, binfo, big["ncams"]), half, ba.parallel.gather_solution(jtr, binfo, big["ncams"]))
+    out["step_calls"] = bred.calls
+    bn.close()
+    if rank == 0:
+        bf = ba.BALNLPModel(arrays=barr, device=0)
+        for tag, ft in (("f64", None), ("f32", np.float32)):
+            d_ref, half_ref, jtr_ref = ba.lm_step(bf, barr[3], 25.0, facto_type=ft)
+            d, half, jtr = steps[tag]
+            out["step_" + tag] = float(np.linalg.norm(d - d_ref) / np.linalg.norm(d_ref))
+            out["half_" + tag] = float(abs(half - half_ref) / half_ref)
+            out["jtr_" + tag] = float(np.max(np.abs(jtr - jtr_ref)) / np.max(np.abs(jtr_ref)))
+        bf.close()
+    # (b) complete LM runs
     prob = ba.synthetic.make_problem(14, 600, 2700, seed=5)
     arrays = ba.synthetic.as_arrays(prob)
     local, info = ba.parallel.shard_problem(arrays, rank, world)
@@ -19,7 +43,7 @@ def main():
     red = ba.parallel.CameraBlockReducer(nlp)
     st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(nlp), "LDL", "AMD", "None", False)
     x = ba.parallel.gather_solution(st.solution, info, prob["ncams"])
-    out = dict(rank=rank, iter=st.iter, objective=st.objective, status=st.status, calls=red.calls)
+    out.update(iter=st.iter, objective=st.objective, status=st.status, calls=red.calls)
     # column scaling needs the GLOBAL column norms of J: diag(Hcc) is all-reduced with gc
     stj = ba.Levenberg_Marquardt(ba.FeasibilityResidual(nlp), "LDL", "AMD", "J", False)
     out.update(iter_j=stj.iter, objective_j=stj.objective, status_j=stj.status)

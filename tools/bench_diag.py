@@ -1,7 +1,7 @@
 import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import __graft_entry__ as ge
-ba = ge.load_package(); L = ba._lib.lib()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _benchlib
+ba, L = _benchlib.load()
 cyc = (C.c_double * 6)(); ms = C.c_double(0)
 L.ba_debug_diag_stamps.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
 rc = L.ba_debug_diag_stamps(cyc, C.byref(ms))

@@ -1,10 +1,10 @@
 """jac_coord micro-benchmark on the Venice shape: 0 real, 1 no arithmetic, 2 no stores, 3 neither."""
 import ctypes as C, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import __graft_entry__ as ge
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _benchlib
 import torch
-ba = ge.load_package(); L = ba._lib.lib()
+ba, L = _benchlib.load()
 name = sys.argv[1] if len(sys.argv) > 1 else "venice-1778"
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 0]
 prob = ba.synthetic.make_named(name)

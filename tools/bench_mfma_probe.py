@@ -2,10 +2,9 @@
 blocks per wave at one wave per SIMD (no staging); 3 = full wave-private staging loop, shipped geometry (64x64 per wave, two
 workgroups per CU), 4 = the same loop with 64x128 per wave, one workgroup per CU."""
 import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import __graft_entry__ as ge
-ba = ge.load_package()
-L = ba._lib.lib()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _benchlib
+ba, L = _benchlib.load()
 L.ba_debug_mfma_probe.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
 for mode in (0, 1, 2, 3, 4, 3, 4):
     tf = C.c_double(0)

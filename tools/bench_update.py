@@ -2,10 +2,9 @@
 variants: 0 real (wave-private LDS staging), 1 store-only epilogue, 2 L2-resident operands, 8 workgroup-shared staging
 with barriers (first version), 9 = 8 + store-only."""
 import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import __graft_entry__ as ge
-ba = ge.load_package()
-L = ba._lib.lib()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _benchlib
+ba, L = _benchlib.load()
 nt = int(sys.argv[1]) if len(sys.argv) > 1 else 126
 L.ba_debug_update_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 m = nt - 2
