@@ -31,17 +31,29 @@ def _cache_path(path, T):
     return path + f".{tag}.balcache.npz"
 
 
+def _source_stamp(path):
+    st = os.stat(path)
+    return np.array([st.st_size, st.st_mtime_ns], dtype=np.int64)
+
+
 def _cache_load(cpath, path, T):
+    """the cached arrays, or None when there is no cache, it is older than / was made from another source file, it is
+    truncated or corrupt, or its arrays are not what readfile(path, T) returns (shapes AND dtypes)"""
+    import zipfile
     try:
         if cpath is None or os.path.getmtime(cpath) < os.path.getmtime(path):
             return None
         with np.load(cpath, allow_pickle=False) as z:
             dims = z["dims"]
+            if "source" not in z.files or not np.array_equal(z["source"], _source_stamp(path)):
+                return None
             out = (z["cam"], z["pnt"], z["pt2d"], z["x0"], int(dims[0]), int(dims[1]), int(dims[2]))
-        ok = (out[0].dtype == np.int64 and out[2].dtype == T and out[0].shape == (out[6],)
-              and out[3].shape == (3 * out[5] + 9 * out[4],))
+        ncams, npnts, nobs = out[4:]
+        ok = (out[0].dtype == np.int64 and out[1].dtype == np.int64 and out[2].dtype == T and out[3].dtype == T
+              and out[0].shape == (nobs,) and out[1].shape == (nobs,) and out[2].shape == (2 * nobs,)
+              and out[3].shape == (3 * npnts + 9 * ncams,))
         return out if ok else None
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, EOFError, zipfile.BadZipFile):
         return None
 
 
@@ -58,7 +70,8 @@ def readfile(filename, T=np.float64):
         try:
             os.makedirs(os.path.dirname(cpath) or ".", exist_ok=True)
             tmp = cpath + f".tmp{os.getpid()}.npz"
-            np.savez(tmp, cam=out[0], pnt=out[1], pt2d=out[2], x0=out[3], dims=np.array(out[4:7], dtype=np.int64))
+            np.savez(tmp, cam=out[0], pnt=out[1], pt2d=out[2], x0=out[3], dims=np.array(out[4:7], dtype=np.int64),
+                     source=_source_stamp(rpath))
             os.replace(tmp, cpath)
         except OSError:
             pass  # read-only data directory: parse every time

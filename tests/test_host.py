@@ -140,3 +140,154 @@ def test_jac_kernel_inflight_registers_untouched():
         pytest.skip("hipcc not available")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_jac_isa.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+REF_LOG = "/root/reference/benchmark/third/lm_linesearch.log"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_LOG), reason="the reference is mounted in the build container only")
+def test_logtrace_parses_reference_benchmark_logs(ba):
+    """benchmark/third/lm_linesearch.log:2-105 -- the published LadyBug-49 run of lm.jl: 57 iterations, final objective
+    13364.31090775441.  The parser must recover the table, the parameters and the execution stats; the comparator must
+    accept the run against itself and flag a flipped accept/reject or a changed digit."""
+    from importlib import import_module
+    lt = import_module(ba.__name__ + ".logtrace")
+    runs = lt.parse_log(open(REF_LOG, encoding="utf-8").read())
+    assert len(runs) == 22
+    r = runs[0]
+    assert r.problem == "LadyBug-49-7776-feasres" and r.first_line == 1
+    assert r.params["facto"] == "LDL" and r.params["perm"] == "AMD" and r.params["linesearch"] is False and r.params["λ"] == 30.0
+    assert r.tolerances["rtol"] == 6.055454452393343e-6
+    assert len(r.rows) == 57 and r.iterations == 57 and r.rows[-1][0] == 57
+    assert r.objective == 13364.31090775441 and r.status == "acceptable" and r.dual_feas == 160.33170664306257
+    assert r.rows[0] == (1, 8.5e5, 0.0, 2.4e7, 4.2e2, 2.1, 1.0, True)
+    assert r.rows[5][7] is False and r.rows[5][6] == -0.19
+    assert abs(r.elapsed_time - 43.60739994049072) < 1e-12
+    # comparator: against itself
+    ok = lt.compare_trace(r.rows, r, objective=r.objective)
+    assert ok["ok"] and ok["rows_compared"] == 57
+    bad = [list(x) for x in r.rows]
+    bad[9][7] = not bad[9][7]
+    res = lt.compare_trace([tuple(x) for x in bad], r)
+    assert not res["ok"] and res["first_mismatch"]["row"] == 9
+    bad = [list(x) for x in r.rows]
+    bad[3][4] *= 1.2
+    assert lt.compare_trace([tuple(x) for x in bad], r)["first_mismatch"]["row"] == 3
+    assert not lt.compare_trace(r.rows, r, objective=r.objective * (1 + 1e-5))["ok"]
+    # a full-precision run prints as its 2-digit row
+    full = [(it, f * 1.004, df * 0.996, g * 1.003, lam * 0.997, d * 1.002, rho, acc) for it, f, df, g, lam, d, rho, acc in r.rows]
+    assert lt.compare_trace(full, r)["rows_compared"] == 57
+
+
+def test_logtrace_roundtrip_of_a_device_style_log(ba):
+    """rows as lm.py returns them -> the reference's text format -> parse -> compare."""
+    from importlib import import_module
+    lt = import_module(ba.__name__ + ".logtrace")
+    rows = [(1, 851234.5, 0.0, 2.41e7, 417.3, 2.13, 0.998, True), (2, 21456.7, 829777.8, 5.4e5, 46.4, 5.06, -0.19, False)]
+    text = "┌ Info: FeasibilityResidual - x\n│   Problem name: T-feasres\n[ Info:   iter      f(x)        Δf     ‖Jᵀr‖         λ       ‖δ‖         ρ           status  \n"
+    text = text
+    for it, f, df, g, lam, d, rho, acc in rows:
+        text += "[ Info: %6d  %8.1e  %8.1e  %8.1e  %8.1e  %8.1e  %8.1e  %15s\n" % (it, f, df, g, lam, d, rho, "acc" if acc else "rej")
+    text += "┌ Info: Generic Execution stats\n│   status: first-order stationary\n│   objective value: 21456.7\n│   iterations: 2\n└   elapsed time: 1.5\n"
+    runs = lt.parse_log(text)
+    assert len(runs) == 1 and len(runs[0].rows) == 2 and runs[0].status == "first_order" and runs[0].objective == 21456.7
+    assert lt.compare_trace(rows, runs[0], objective=21456.7)["ok"]
+
+
+@pytest.mark.parametrize("ext", [".txt", ".txt.bz2"])
+def test_reader_streams_through_a_small_window(ba, small_prob, tmp_path, ext, monkeypatch):
+    """The reader decodes the file chunk by chunk into a fixed window (8 MiB) and parses as it goes; with a 4 KiB window
+    a 300 KB file is refilled ~80 times and every token still parses identically (no number straddles a refill)."""
+    p = small_prob
+    path = str(tmp_path / "Synth" / ("problem-12-400-pre" + ext))
+    ba.synthetic.write_bal(path, p)
+    monkeypatch.setenv("BA_READ_CACHE", "0")
+    monkeypatch.setenv("BA_READER_WINDOW", "4096")
+    cam, pnt, pt2d, x0, ncams, npnts, nobs = ba.readfile(path)
+    assert (ncams, npnts, nobs) == (p["ncams"], p["npnts"], p["nobs"])
+    assert np.array_equal(cam, p["cam_idx1"]) and np.array_equal(pnt, p["pnt_idx1"])
+    assert np.array_equal(pt2d, p["pt2d"]) and np.array_equal(x0, p["x0"])
+    # truncated in the middle of the camera block: refused, not silently short
+    data = open(path, "rb").read() if ext == ".txt" else None
+    if data is not None:
+        cut = str(tmp_path / "cut.txt")
+        with open(cut, "wb") as fh:
+            fh.write(data[: len(data) // 2])
+        with pytest.raises(ba.BAError):
+            ba.readfile(cut)
+
+
+def test_reader_cache_corrupt_or_foreign_is_ignored(ba, small_prob, tmp_path):
+    """A truncated cache (BadZipFile), a cache with the wrong dtypes, and one made from another source file must all be
+    ignored and the file parsed again."""
+    p = small_prob
+    path = str(tmp_path / "Synth" / "problem-12-400-pre.txt")
+    ba.synthetic.write_bal(path, p)
+    a = ba.readfile(path)
+    cache = path + ".f64.balcache.npz"
+    blob = open(cache, "rb").read()
+    os.utime(path, (1, 1))  # keep the source older than whatever cache is written below
+    # source stamp changed -> the cache belongs to another file
+    assert ba.readfiles._cache_load(cache, path, np.float64) is None
+    ba.readfile(path)  # rewrites the cache for the new stamp
+    assert ba.readfiles._cache_load(cache, path, np.float64) is not None
+    with open(cache, "wb") as fh:
+        fh.write(blob[: len(blob) // 3])
+    b = ba.readfile(path)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    z = dict(np.load(cache))
+    z["x0"] = z["x0"].astype(np.float32)
+    np.savez(cache[:-4], **z)
+    assert ba.readfiles._cache_load(cache, path, np.float64) is None
+    z["x0"] = z["x0"].astype(np.float64)
+    z["pnt"] = z["pnt"].astype(np.int32)
+    np.savez(cache[:-4], **z)
+    assert ba.readfiles._cache_load(cache, path, np.float64) is None
+
+
+def test_c_abi_from_plain_c(ba, small_prob, tmp_path):
+    """include/ba_hip.h compiles as C99 (-pedantic -Werror), libba_hip.so links from C, and the struct layouts the
+    foreign-function bindings mirror by hand (ctypes here, the Julia structs in julia/) equal the C compiler's."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    libdir = os.path.dirname(ba._lib.LIB_PATH)
+    exe = str(tmp_path / "abi_check")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "abi_check.c"), "-L", libdir, "-lba_hip",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    bal = str(tmp_path / "Synth" / "problem-12-400-pre.txt.bz2")
+    ba.synthetic.write_bal(bal, small_prob)
+    r = subprocess.run([exe, bal], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sizes, offs = {}, {}
+    for line in r.stdout.splitlines():
+        w = line.split()
+        if w[0] == "sizeof":
+            sizes[w[1]] = int(w[2])
+        elif w[0] == "offsetof":
+            offs[(w[1], w[2])] = int(w[3])
+    for cname, cls in (("ba_lm_opts", ba._lib.LMOpts), ("ba_lm_stats", ba._lib.LMStats)):
+        assert sizes[cname] == ctypes.sizeof(cls)
+        names = [f[0] for f in cls._fields_]
+        c_names = [k[1] for k in offs if k[0] == cname]
+        assert len(names) == len(c_names)
+        for fname in names:
+            c_field = {"lam": "lambda"}.get(fname, fname)
+            assert offs[(cname, c_field)] == getattr(cls, fname).offset, (cname, fname)
+    p = small_prob
+    assert f"ncams {p['ncams']} npnts {p['npnts']} nobs {p['nobs']}" in r.stdout
+    assert "ba_read_bal rc 0" in r.stdout and "ba_problem_dims(NULL) rc 1" in r.stdout
+
+
+def test_product_library_has_no_probe_entries(ba):
+    """micro-benchmark / probe entry points live in tools/libba_bench.so (csrc/bench/), not in the product library"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", ba._lib.LIB_PATH], capture_output=True, text=True).stdout
+    syms = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert not [s for s in syms if s.startswith("ba_debug")]
+    exported = {s for s in syms if s.startswith("ba_")} - {"ba_set_error"}
+    assert exported == set(ba._lib.SYMBOLS), exported ^ set(ba._lib.SYMBOLS)
