@@ -27,7 +27,7 @@ class SQDException(BAError):
 
 class LMOpts(C.Structure):
     _fields_ = [("variant", C.c_int), ("facto", C.c_int), ("normalize", C.c_int), ("linesearch", C.c_int),
-                ("facto_f32", C.c_int), ("ite_max", C.c_int), ("verbose", C.c_int), ("x_f32", C.c_int),
+                ("facto_type", C.c_int), ("ite_max", C.c_int), ("verbose", C.c_int), ("x_f32", C.c_int),
                 ("restol", C.c_double), ("satol", C.c_double), ("srtol", C.c_double), ("oatol", C.c_double),
                 ("ortol", C.c_double), ("atol", C.c_double), ("rtol", C.c_double),
                 ("nu_d", C.c_double), ("nu_m", C.c_double), ("lam", C.c_double), ("delta_d", C.c_double),

@@ -579,6 +579,10 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     ba_set_error("ba_lm_solve: facto must be 0 (:LDL) or 1 (:QR)");
     return BA_ERR_ARG;
   }
+  if (o->facto_type < 0 || o->facto_type > 1) {
+    ba_set_error("ba_lm_solve: facto_type must be 0 (eltype(x)) or 1 (Float32); the Float16 path of src/lm.jl:165-169 is not provided");
+    return BA_ERR_ARG;
+  }
   if (o->normalize < 0 || o->normalize > 2) {
     ba_set_error("ba_lm_solve: normalize must be 0 (:None), 1 (:J) or 2 (:A)");
     return BA_ERR_ARG;
@@ -637,7 +641,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   while (!(small_step || first_order || small_residual || small_obj_change || tired || fail2)) {
     if (V) iter++;                                                                           // lm.jl:127
     if (!V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);  // LevenbergMarquardt.jl:143-147
-    if ((rc = trial_step(p, w, lambda, o->normalize, V && o->facto_f32, xf32, st)) != BA_OK) break;  // lm.jl:154-254
+    if ((rc = trial_step(p, w, lambda, o->normalize, V && o->facto_type == 1, xf32, st)) != BA_OK) break;  // lm.jl:154-254
     stats->n_factor++;
     stats->n_residual++;
     if (*w->h_flag == 2) {

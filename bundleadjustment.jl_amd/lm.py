@@ -82,7 +82,7 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
         return -1.0 if v is None else float(v)
 
     o = _lib.LMOpts(variant=variant, facto=_FACTO[facto], normalize=_NORM[normalize], linesearch=int(bool(linesearch)),
-                    facto_f32=int(f32), ite_max=-1 if ite_max is None else int(ite_max), verbose=int(verbose), x_f32=int(xf32),
+                    facto_type=int(f32), ite_max=-1 if ite_max is None else int(ite_max), verbose=int(verbose), x_f32=int(xf32),
                     restol=d(restol), satol=d(satol), srtol=d(srtol), oatol=d(oatol), ortol=d(ortol), atol=d(atol),
                     rtol=d(rtol), nu_d=d(nu_d), nu_m=d(nu_m), lam=d(lam), delta_d=d(delta_d), max_time=d(max_time))
     st = _lib.LMStats()

@@ -17,7 +17,7 @@
 int main(int argc, char **argv) {
   printf("sizeof ba_lm_opts %zu\n", sizeof(ba_lm_opts));
   OFF(ba_lm_opts, variant); OFF(ba_lm_opts, facto); OFF(ba_lm_opts, normalize); OFF(ba_lm_opts, linesearch);
-  OFF(ba_lm_opts, facto_f32); OFF(ba_lm_opts, ite_max); OFF(ba_lm_opts, verbose); OFF(ba_lm_opts, x_f32);
+  OFF(ba_lm_opts, facto_type); OFF(ba_lm_opts, ite_max); OFF(ba_lm_opts, verbose); OFF(ba_lm_opts, x_f32);
   OFF(ba_lm_opts, restol); OFF(ba_lm_opts, satol); OFF(ba_lm_opts, srtol); OFF(ba_lm_opts, oatol);
   OFF(ba_lm_opts, ortol); OFF(ba_lm_opts, atol); OFF(ba_lm_opts, rtol); OFF(ba_lm_opts, nu_d); OFF(ba_lm_opts, nu_m);
   OFF(ba_lm_opts, lambda); OFF(ba_lm_opts, delta_d); OFF(ba_lm_opts, max_time);

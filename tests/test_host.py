@@ -291,3 +291,29 @@ def test_product_library_has_no_probe_entries(ba):
     assert not [s for s in syms if s.startswith("ba_debug")]
     exported = {s for s in syms if s.startswith("ba_")} - {"ba_set_error"}
     assert exported == set(ba._lib.SYMBOLS), exported ^ set(ba._lib.SYMBOLS)
+
+
+def test_julia_shim_matches_header(ba):
+    """julia/BALHIP.jl cannot be executed here (no Julia in the image): its struct field lists are compared with the
+    ctypes mirrors, which test_c_abi_from_plain_c ties to the C compiler's layout; every ccall symbol must be exported."""
+    src = {f: open(os.path.join(ROOT, "julia", f), encoding="utf-8").read()
+           for f in ("BALHIP.jl", "BALNLPModelsHIP.jl", "LevenbergMarquardtHIP.jl", "solve_ba_hip.jl")}
+    jl_types = {"Cint": ctypes.c_int, "Cdouble": ctypes.c_double}
+
+    def fields(struct):
+        body = re.search(r"struct " + struct + r"\n(.*?)\n(?:  " + struct + r"\(\)|end)", src["BALHIP.jl"], re.S).group(1)
+        return [(m.group(1), jl_types[m.group(2)]) for m in re.finditer(r"^\s+(\w+) :: (\w+)\s*$", body, re.M)]
+
+    for jname, cls in (("BaLmOpts", ba._lib.LMOpts), ("BaLmStats", ba._lib.LMStats)):
+        got = fields(jname)
+        want = [({"lam": "lambda"}.get(n, n), t) for n, t in cls._fields_]
+        assert got == want, (jname, got, want)
+    called = set(re.findall(r"ccall\(\(:(\w+), libba\)", "".join(src.values())))
+    assert called and called <= set(ba._lib.SYMBOLS), called - set(ba._lib.SYMBOLS)
+    # both reference signatures exist: 5 positional arguments (src/lm.jl:15-19) and 4 (src/LevenbergMarquardt.jl:16-19)
+    lm = src["LevenbergMarquardtHIP.jl"]
+    assert re.search(r"function Levenberg_Marquardt\(model :: AbstractNLSModel, facto :: Symbol, perm :: Symbol, normalize :: Symbol,\s+linesearch :: Bool;", lm)
+    assert re.search(r"function Levenberg_Marquardt\(model :: AbstractNLSModel, facto :: Symbol, perm :: Symbol, normalize :: Symbol;", lm)
+    for needed in ("NLPModels.cons!", "NLPModels.jac_structure!", "NLPModels.jac_coord!", "function name(", "function readfile(",
+                   "Vector{Float32}"):
+        assert needed in src["BALNLPModelsHIP.jl"]
