@@ -96,37 +96,36 @@ __device__ inline float fast_recip<float>(float d) {
   return x;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__restrict__ Linv_k,
-                                                   T *__restrict__ D_k, int *__restrict__ flag,
-                                                   unsigned long long *__restrict__ stamps,
-                                                   const int *__restrict__ wait_ready) {
-  BA_VT
-  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-  T *sm = reinterpret_cast<T *>(smraw);
-  if (wait_ready) {
-    // Hoisted launch: this workgroup was started early (while CUs were free) and waits here until the trailing update
-    // running beside it has finished this tile (k_ldl_update, tile 0, release at agent scope).  Bounded: after ~0.5 s of
-    // polling it gives up and reports through the pivot flag, so the wave always reaches its exit.
-    __shared__ int ok;
-    if (threadIdx.x == 0) {
-      int seen = 0;
-      const bool abandoned = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2;  // an earlier tile gave up
-      for (unsigned n = 0; n < (1u << 17) && !abandoned; n++) {
-        // relaxed poll: an acquire at agent scope invalidates this XCD's L2 on every iteration, which the trailing
-        // update running on the same XCD pays for (n = 40000: 421-426 ms against 411 ms without the hoist); the one
-        // acquire that matters is the fence after the loop
-        seen = __hip_atomic_load(wait_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen) break;
-        __builtin_amdgcn_s_sleep(127);
-      }
-      ok = seen;
-      if (!seen) *flag = 2;
+// bounded wait of a hoisted workgroup for `need` tiles of the trailing update running beside it (k_ldl_update raises
+// *wait_ready once per finished tile, release at agent scope).  Returns false when the wait was abandoned: after ~0.5 s of
+// polling it gives up and reports through the pivot flag (value 2), so the wave always reaches its exit.
+__device__ inline bool hoisted_wait(const int *wait_ready, int need, int *flag) {
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    int seen = 0;
+    const bool abandoned = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2;  // an earlier tile gave up
+    for (unsigned n = 0; n < (1u << 17) && !abandoned; n++) {
+      // relaxed poll: an acquire at agent scope invalidates caches on every iteration, which the trailing update running
+      // on the same XCD pays for (n = 40000: 421-426 ms against 411 ms without the hoist); the one acquire that matters
+      // is the fence after the loop
+      seen = __hip_atomic_load(wait_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen >= need) break;
+      __builtin_amdgcn_s_sleep(127);
     }
-    __syncthreads();
-    if (!ok) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every thread: the tile's lines are re-read from memory
+    ok = seen >= need;
+    if (!ok) *flag = 2;
   }
+  __syncthreads();
+  if (!ok) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every thread: the tiles' lines are re-read from memory
+  return true;
+}
+
+// factor one diagonal tile in the workgroup's LDS image `sm` (DIAG_LDS_ELEMS elements): see the section comment above
+template <typename T>
+__device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T *__restrict__ D_k, int *__restrict__ flag,
+                                 unsigned long long *__restrict__ stamps, T *sm) {
+  BA_VT
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;  // diagnostic phase timers (stamps != null only)
 #define STAMP(slot)                                        \
   if (stamps) {                                            \
@@ -299,6 +298,18 @@ __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__rest
 #undef STAMP
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__restrict__ Linv_k,
+                                                   T *__restrict__ D_k, int *__restrict__ flag,
+                                                   unsigned long long *__restrict__ stamps,
+                                                   const int *__restrict__ wait_ready) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  // hoisted launch: started early (while CUs were free), waits in place until the trailing update running beside it has
+  // finished this tile
+  if (wait_ready && !hoisted_wait(wait_ready, 1, flag)) return;
+  diag_tile<T>(Skk, Linv_k, D_k, flag, stamps, reinterpret_cast<T *>(smraw));
+}
+
 // ---- 128 x 128 x (128 NP) tile product C = sum_p A_p * B_p' on the matrix cores ------------------------------------
 // A_p, B_p: contiguous row-major 128x128 tiles in global memory.  256 threads = 4 waves, wave w owns the 64x64
 // quadrant (w >> 1, w & 1) as 4x4 MFMA blocks (128 accumulator VGPRs).  K is consumed in chunks of KC = 16 staged
@@ -456,43 +467,42 @@ __device__ inline void tile_gemm_abt_priv(const T *__restrict__ A0, const T *__r
 // RS = 32 rows of a tile (4 waves x (32 rows x 32 columns) = 2x2 MFMA blocks each), so 4x as many workgroups run
 // concurrently and each is ~4x shorter.
 constexpr int RS = 32;
-constexpr size_t RS_LDS_ELEMS = (size_t)((RS + NB) * LDK + 5 * NB);
+constexpr size_t RS_LDS_ELEMS = (size_t)(2 * (RS + NB) * LDK + 5 * NB);
 
-template <typename T, bool YACC, int NP = 1>
+// Latency is what these 32-row products cost (a chunk's MFMAs take ~0.4 us, a global load 1-2 us): ALL of the K range
+// (8 chunks of KC) is requested up front -- 80 VGPRs of loads in flight, the latency is paid once -- and the chunks pass
+// through a two-buffer LDS ring with ONE barrier each (a wave reaches barrier ch only after its MFMAs of chunk ch-1, so
+// buffer (ch+1)&1 is free to be overwritten once barrier ch has been passed).
+// LDS: sA = 2 x RS x LDK, sB = 2 x NB x LDK.
+template <typename T, bool YACC>
 __device__ inline void tile_gemm_rows(const T *__restrict__ A, const T *__restrict__ B, T *sA, T *sB,
-                                      typename RT<T>::v4 acc[2][2], const T *__restrict__ bk, T *yacc,
-                                      const T *__restrict__ A1 = nullptr, const T *__restrict__ B1 = nullptr) {
+                                      typename RT<T>::v4 acc[2][2], const T *__restrict__ bk, T *yacc) {
   BA_VT
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wc = wv * 32;
   const int fr = lane & 15, fk = lane >> 4;
   constexpr int UPR = KC / 2;
   const int lrow = tid / UPR, lc2 = tid % UPR;  // 256 threads cover 32 rows x (KC/2) 16-byte units
-  d2 pa, pb[4];
-  pa = *reinterpret_cast<const d2 *>(A + lrow * NB + 2 * lc2);
+  constexpr int NCH = NB / KC;
+  d2 pa[NCH], pb[NCH][4];
 #pragma unroll
-  for (int it = 0; it < 4; it++) pb[it] = *reinterpret_cast<const d2 *>(B + (lrow + 32 * it) * NB + 2 * lc2);
-  constexpr int NCH = NP * (NB / KC);
   for (int ch = 0; ch < NCH; ch++) {
-    __syncthreads();
-    *reinterpret_cast<d2 *>(sA + lrow * LDK + 2 * lc2) = pa;
+    pa[ch] = *reinterpret_cast<const d2 *>(A + lrow * NB + ch * KC + 2 * lc2);
 #pragma unroll
-    for (int it = 0; it < 4; it++) *reinterpret_cast<d2 *>(sB + (lrow + 32 * it) * LDK + 2 * lc2) = pb[it];
-    __syncthreads();
-    if (ch + 1 < NCH) {
-      const int nx = ch + 1;
-      const T *An = (NP == 2 && nx >= NB / KC) ? A1 : A;
-      const T *Bn = (NP == 2 && nx >= NB / KC) ? B1 : B;
-      const int k0 = (nx & (NB / KC - 1)) * KC;
-      pa = *reinterpret_cast<const d2 *>(An + lrow * NB + k0 + 2 * lc2);
+    for (int it = 0; it < 4; it++) pb[ch][it] = *reinterpret_cast<const d2 *>(B + (lrow + 32 * it) * NB + ch * KC + 2 * lc2);
+  }
 #pragma unroll
-      for (int it = 0; it < 4; it++) pb[it] = *reinterpret_cast<const d2 *>(Bn + (lrow + 32 * it) * NB + k0 + 2 * lc2);
-    }
+  for (int ch = 0; ch < NCH; ch++) {
+    T *cA = sA + (ch & 1) * RS * LDK, *cB = sB + (ch & 1) * NB * LDK;
+    *reinterpret_cast<d2 *>(cA + lrow * LDK + 2 * lc2) = pa[ch];
+#pragma unroll
+    for (int it = 0; it < 4; it++) *reinterpret_cast<d2 *>(cB + (lrow + 32 * it) * LDK + 2 * lc2) = pb[ch][it];
+    __syncthreads();
     if (YACC) {
       if (tid < NB) {
         T ya = *yacc;
 #pragma unroll
-        for (int q = 0; q < KC; q++) ya += sB[tid * LDK + q] * bk[ch * KC + q];
+        for (int q = 0; q < KC; q++) ya += cB[tid * LDK + q] * bk[ch * KC + q];
         *yacc = ya;
       }
     }
@@ -500,15 +510,16 @@ __device__ inline void tile_gemm_rows(const T *__restrict__ A, const T *__restri
     for (int kk = 0; kk < KC / 4; kk++) {
       T af[2], bf[2];
 #pragma unroll
-      for (int m = 0; m < 2; m++) af[m] = sA[(16 * m + fr) * LDK + kk * 4 + fk];
+      for (int m = 0; m < 2; m++) af[m] = cA[(16 * m + fr) * LDK + kk * 4 + fk];
 #pragma unroll
-      for (int n = 0; n < 2; n++) bf[n] = sB[(wc + 16 * n + fr) * LDK + kk * 4 + fk];
+      for (int n = 0; n < 2; n++) bf[n] = cB[(wc + 16 * n + fr) * LDK + kk * 4 + fk];
 #pragma unroll
       for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++) acc[m][n] = RT<T>::mfma(af[m], bf[n], acc[m][n]);
     }
   }
+  __syncthreads();  // the ring (and whatever the caller keeps beside it) may be rewritten from here on
 }
 
 // rows [32 rq, 32 rq + 32) of X_i = S_ik Linv_k' -> V_i, S_ik = X_i D_k^-1; FWD: y_k and b_i -= L_ik y_k ride along.
@@ -520,7 +531,7 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const in
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
-  T *sA = lds, *sB = lds + RS * LDK, *ysh = lds + (RS + NB) * LDK, *red = ysh + NB;  // red: 4 x 32
+  T *sA = lds, *sB = lds + 2 * RS * LDK, *ysh = lds + 2 * (RS + NB) * LDK, *red = ysh + NB;  // red: 4 x 32
   const int i = k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
   T *Sik = S + tix(co, i, k) * NB * NB + r0 * NB;
   T *Vi = V + (int64_t)i * NB * NB + r0 * NB;
@@ -583,7 +594,7 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
-  T *sA = lds, *sB = lds + RS * LDK;
+  T *sA = lds, *sB = lds + 2 * RS * LDK;
   const int i = k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
   typename RT<T>::v4 acc[2][2];
 #pragma unroll
@@ -606,6 +617,260 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int
   }
 }
 
+// ---- fused panel-pair kernels (pair schedule) ------------------------------------------------------------------------------
+// The panel chain of a pair (k, k+1) -- diag(k), panel solve of column k, update of column k+1, diag(k+1), panel solve of
+// column k+1 -- has only TWO steps that are inherently sequential workgroup-sized jobs, the two diagonal tiles, and the
+// second one needs nothing of panel k but tile row k+1.  k_ldl_pairdiag does everything that involves only the three
+// tiles (k,k), (k+1,k), (k+1,k+1) in ONE workgroup:
+//     diag(k);  X = S_{k+1,k} Linv_k';  V0_{k+1} = X, L_{k+1,k} = X D_k^-1;  S_{k+1,k+1} -= X L_{k+1,k}';  diag(k+1)
+// (+ the forward substitution of rows k, k+1), so that it can be hoisted as a whole beside the previous pair's trailing
+// update (it needs that update's first three tiles only).  What is left on the critical path is ONE row-parallel kernel,
+// k_ldl_pairtrsm: for every 32-row slice of the tile rows i >= k+2
+//     X0 = S_ik Linv_k';  S_{i,k+1} -= X0 L_{k+1,k}';  X1 = S_{i,k+1} Linv_{k+1}'      (X0, then the updated slice, stay in LDS)
+// and the forward substitution of its rows: b_i -= L_ik y_k + L_{i,k+1} y_{k+1}.
+constexpr int LDX = NB + 4;  // row stride of the 32 x 128 slice kept in LDS between the stages (264 dwords = 8 mod 64)
+constexpr size_t PT_LDS_ELEMS = (size_t)(RS * LDX + 2 * NB * LDK + 2 * NB + 4 * RS);  // 73.7 KB in f64: two workgroups per CU
+
+// C(32 x 128, distributed like tile_gemm_rows) = A B' with the 32 x 128 A slice already in LDS (sX, stride LDX) and the B
+// tile streamed from global memory in chunks of KC through sB
+template <typename T>
+__device__ inline void tile_gemm_rows_ldsA(const T *sX, const T *__restrict__ B, T *sB, typename RT<T>::v4 acc[2][2]) {
+  BA_VT
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wc = wv * 32;
+  const int fr = lane & 15, fk = lane >> 4;
+  constexpr int UPR = KC / 2;
+  const int lrow = tid / UPR, lc2 = tid % UPR;
+  constexpr int NCH = NB / KC;
+  d2 pb[NCH][4];  // the whole B tile is requested up front (see tile_gemm_rows)
+#pragma unroll
+  for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+    for (int it = 0; it < 4; it++) pb[ch][it] = *reinterpret_cast<const d2 *>(B + (lrow + 32 * it) * NB + ch * KC + 2 * lc2);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ch++) {
+    T *cB = sB + (ch & 1) * NB * LDK;
+#pragma unroll
+    for (int it = 0; it < 4; it++) *reinterpret_cast<d2 *>(cB + (lrow + 32 * it) * LDK + 2 * lc2) = pb[ch][it];
+    __syncthreads();  // also orders the caller's writes of sX before the first chunk's reads
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; kk++) {
+      T af[2], bf[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++) af[m] = sX[(16 * m + fr) * LDX + ch * KC + kk * 4 + fk];
+#pragma unroll
+      for (int n = 0; n < 2; n++) bf[n] = cB[(wc + 16 * n + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) acc[m][n] = RT<T>::mfma(af[m], bf[n], acc[m][n]);
+    }
+  }
+  __syncthreads();  // every wave has finished reading sX and the ring
+}
+
+// grid = 4 (nt-k-2): i = k + 2 + blockIdx.x / 4, rows [32 rq, 32 rq + 32), rq = blockIdx.x % 4.  y: y_k | y_{k+1} at y + k NB.
+template <typename T, bool FWD>
+__global__ __launch_bounds__(256) void k_ldl_pairtrsm(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
+                                                       const T *__restrict__ D, T *__restrict__ V0, T *__restrict__ V1, int k,
+                                                       T *__restrict__ b, const T *__restrict__ y) {
+  BA_VT
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  T *sX = lds, *sB = sX + RS * LDX, *ysh = sB + 2 * NB * LDK, *red = ysh + 2 * NB;  // red: 4 x 32
+  const int i = k + 2 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wc = wv * 32;
+  T *Sik = S + tix(co, i, k) * NB * NB + r0 * NB;
+  T *Sik1 = S + tix(co, i, k + 1) * NB * NB + r0 * NB;
+  T *Vi0 = V0 + (int64_t)i * NB * NB + r0 * NB, *Vi1 = V1 + (int64_t)i * NB * NB + r0 * NB;
+  const T *Dk = D + (int64_t)k * NB, *Dk1 = Dk + NB;
+  if (FWD) ysh[tid] = y[(int64_t)k * NB + tid];  // y_k | y_{k+1} (256 values); ordered by the barriers of the first product
+  typename RT<T>::v4 acc[2][2];
+  T part[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) part[m][g] = 0;
+  // ---- stage 1: X0 = S_ik Linv_k'
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  {  // the 32 x 128 slice of S_ik goes to LDS whole (16 loads of 16 bytes per thread in flight)
+    d2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const d2 *>(Sik + 2 * (q * 256 + tid));
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int idx = 2 * (q * 256 + tid);
+      *reinterpret_cast<d2 *>(sX + (idx >> 7) * LDX + (idx & (NB - 1))) = v[q];
+    }
+  }
+  tile_gemm_rows_ldsA<T>(sX, Linv + (int64_t)k * NB * NB, sB, acc);
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int col = wc + 16 * n + (lane & 15);
+    const T inv_d = (T)1 / Dk[col];
+    const T wcol = FWD ? ysh[col] * inv_d : (T)0;
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = 16 * m + RT<T>::row(lane, g);
+        const T xv = acc[m][n][g];
+        Vi0[row * NB + col] = xv;
+        Sik[row * NB + col] = xv * inv_d;
+        sX[row * LDX + col] = xv;
+        if (FWD) part[m][g] += xv * wcol;
+      }
+  }
+  // ---- stage 2: C = S_{i,k+1} - X0 L_{k+1,k}'   (the barriers inside the product order the sX writes above)
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  tile_gemm_rows_ldsA<T>(sX, S + tix(co, k + 1, k) * NB * NB, sB, acc);  // returns after every wave has finished reading X0
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int col = wc + 16 * n + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = 16 * m + RT<T>::row(lane, g);
+        sX[row * LDX + col] = Sik1[row * NB + col] - acc[m][n][g];
+      }
+  }
+  // ---- stage 3: X1 = C Linv_{k+1}'
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  tile_gemm_rows_ldsA<T>(sX, Linv + (int64_t)(k + 1) * NB * NB, sB, acc);
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int col = wc + 16 * n + (lane & 15);
+    const T inv_d = (T)1 / Dk1[col];
+    const T wcol = FWD ? ysh[NB + col] * inv_d : (T)0;
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = 16 * m + RT<T>::row(lane, g);
+        const T xv = acc[m][n][g];
+        Vi1[row * NB + col] = xv;
+        Sik1[row * NB + col] = xv * inv_d;
+        if (FWD) part[m][g] += xv * wcol;
+      }
+  }
+  if (FWD) {  // b_i -= L_ik y_k + L_{i,k+1} y_{k+1} for this slice's rows: fixed tree (16 lanes, then the 4 waves)
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        T v = part[m][g];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if ((lane & 15) == 0) red[wv * RS + 16 * m + RT<T>::row(lane, g)] = v;
+      }
+    __syncthreads();
+    if (tid < RS) b[(int64_t)i * NB + r0 + tid] -= ((red[tid] + red[RS + tid]) + red[2 * RS + tid]) + red[3 * RS + tid];
+  }
+}
+
+// one workgroup: the three tiles (k,k), (k+1,k), (k+1,k+1) of a pair (see above).  wait_ready / need: hoisted launch.
+template <typename T, bool FWD>
+__global__ __launch_bounds__(256) void k_ldl_pairdiag(T *__restrict__ S, const int64_t *__restrict__ co, T *__restrict__ Linv,
+                                                       T *__restrict__ D, T *__restrict__ V0, int k, int nt,
+                                                       int *__restrict__ flag, const int *__restrict__ wait_ready, int need,
+                                                       T *__restrict__ b, T *__restrict__ y) {
+  BA_VT
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *sm = reinterpret_cast<T *>(smraw);
+  if (wait_ready && !hoisted_wait(wait_ready, need, flag)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  T *Skk = S + tix(co, k, k) * NB * NB, *Lk = Linv + (int64_t)k * NB * NB, *Dk = D + (int64_t)k * NB;
+  diag_tile<T>(Skk, Lk, Dk, flag, nullptr, sm);
+  __threadfence();  // this workgroup re-reads what it has just written (Linv_k now, L_{k+1,k} and V0_{k+1} below) from memory
+  __syncthreads();
+  T *ysh = sm + 2 * NB * LDK;  // behind the product's staging area
+  if (FWD) {  // y_k = Linv_k b_k  (unit lower triangular: columns <= row)
+    if (tid < NB) {
+      T sacc = 0;
+      for (int c = 0; c <= tid; c++) sacc += Lk[tid * NB + c] * b[(int64_t)k * NB + c];
+      ysh[tid] = sacc;
+      y[(int64_t)k * NB + tid] = sacc;
+    }
+    __syncthreads();
+  }
+  if (k + 1 >= nt) return;
+  T *S10 = S + tix(co, k + 1, k) * NB * NB, *S11 = S + tix(co, k + 1, k + 1) * NB * NB;
+  T *V10 = V0 + (int64_t)(k + 1) * NB * NB;
+  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  typename RT<T>::v4 acc[4][4];
+  // X = S_{k+1,k} Linv_k' -> V0_{k+1}, L_{k+1,k} = X D_k^-1
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  tile_gemm_abt<T, 1>(S10, Lk, nullptr, nullptr, sm, sm + NB * LDK, acc);
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const int col = wc + 16 * n + (lane & 15);
+    const T inv_d = (T)1 / Dk[col];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = wr + 16 * m + RT<T>::row(lane, g);
+        const T xv = acc[m][n][g];
+        V10[row * NB + col] = xv;
+        S10[row * NB + col] = xv * inv_d;
+      }
+  }
+  __threadfence();
+  __syncthreads();
+  if (FWD) {  // b_{k+1} -= L_{k+1,k} y_k
+    if (tid < NB) {
+      T sacc = 0;
+      for (int c = 0; c < NB; c++) sacc += S10[tid * NB + c] * ysh[c];
+      b[(int64_t)(k + 1) * NB + tid] -= sacc;
+    }
+  }
+  // S_{k+1,k+1} -= X L_{k+1,k}'
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  tile_gemm_abt<T, 1>(V10, S10, nullptr, nullptr, sm, sm + NB * LDK, acc);
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const int col = wc + 16 * n + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = wr + 16 * m + RT<T>::row(lane, g);
+        S11[row * NB + col] -= acc[m][n][g];
+      }
+  }
+  __threadfence();
+  __syncthreads();
+  T *Lk1 = Lk + NB * NB, *Dk1 = Dk + NB;
+  diag_tile<T>(S11, Lk1, Dk1, flag, nullptr, sm);
+  if (FWD) {  // y_{k+1} = Linv_{k+1} b_{k+1}
+    __threadfence();
+    __syncthreads();
+    if (tid < NB) {
+      T sacc = 0;
+      for (int c = 0; c <= tid; c++) sacc += Lk1[tid * NB + c] * b[(int64_t)(k + 1) * NB + c];
+      y[(int64_t)(k + 1) * NB + tid] = sacc;
+    }
+  }
+}
+
 // Bulk trailing update, two panels per pass:  S_ij -= V0_i L_jk' + V1_i L_{j,k+1}'  for the lower-triangular tile pairs
 // base <= j <= i (K = 256): the trailing matrix is read and written once per TWO panels, which halves its HBM traffic per
 // flop.  (MODE is kept as a template parameter for the micro-benchmark variants; only MODE 1 exists.)
@@ -625,19 +890,20 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
                                                         int nblk, int *__restrict__ ready,
                                                         const int *__restrict__ own_cols = nullptr,
                                                         const int64_t *__restrict__ own_pref = nullptr, int m0 = 0,
-                                                        int m_end = 0) {
+                                                        int m_end = 0, int ready_tiles = 1) {
   BA_VT
   static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
   T *sA = lds, *sB = lds + NB * LDK;
-  int i, j;
+  int i, j, tsel;
   {
     // chunked block -> XCD map: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous
     // range of tile rows so that V_i stays in its L2 (speed only)
     const int per = (nblk + 7) / 8;
     int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (t >= nblk) return;
+    tsel = t;
     if (OWN) {
       const int64_t tt = t + own_pref[m0];
       int lo = m0, hi = m_end;  // largest m with own_pref[m] <= tt
@@ -699,10 +965,12 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
           else cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)] = nv;
         }
   }
-  if (ready && i == base && j == base) {  // the next diagonal tile is final: tell the workgroup waiting to factor it
-    __threadfence();                        // every thread's stores, agent scope (written back past this XCD's L2)
+  // tiles 0 .. ready_tiles-1 are (base,base) [, (base+1,base), (base+1,base+1)]: what the next pair's hoisted diagonal
+  // kernel waits for.  Each tells it so once its tile is final.
+  if (ready && tsel < ready_tiles) {
+    __threadfence();  // every thread's stores, agent scope (written back past this XCD's L2)
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -818,6 +1086,14 @@ static int set_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_pairdiag<T, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_pairdiag<T, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_pairtrsm<T, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PT_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_pairtrsm<T, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PT_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 0, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
   g_attr_done = true;
@@ -944,13 +1220,46 @@ static int launch_col(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0, hipStr
 // is final (hoisted-diagonal schedule)
 template <typename T>
 static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, const T *V0, const T *V1, hipStream_t st,
-                       int *ready = nullptr) {
+                       int *ready = nullptr, int ready_tiles = 1) {
   const int nt = (int)w->nt, m = nt - base;
   if (m <= 0) return BA_OK;
   ProfScope ps(p, PC_LDL_UPDATE, st);
   const int nblk = m * (m + 1) / 2;
+  // (Cutting the tiles of a partly filled last round into 64 x 64 quadrants, one workgroup each, was tried and removed:
+  // 34.1-34.3 ms against 33.9-34.1 at n = 16 002.  A partial round does not cost a full one -- the quadrant kernel took
+  // 39 us on average, which is what the big kernel's own last round costs.)
   hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st, w->S,
-                     w->col_off, V0, V1, k, base, nt, nblk, ready);
+                     w->col_off, V0, V1, k, base, nt, nblk, ready, (const int *)nullptr, (const int64_t *)nullptr, 0, 0,
+                     ready_tiles);
+  return BA_OK;
+}
+
+// the fused panel-pair kernels (see k_ldl_pairdiag): b != null: forward substitution rides along
+template <typename T>
+static int launch_pairdiag(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *b, hipStream_t st, const int *wait_ready, int need) {
+  ProfScope ps(p, PC_LDL_DIAG, st);
+  T *y = w->D + w->nt * NB;
+  if (b)
+    hipLaunchKernelGGL((k_ldl_pairdiag<T, true>), dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, w->Linv, w->D,
+                       V0, k, (int)w->nt, w->flag, wait_ready, need, b, y);
+  else
+    hipLaunchKernelGGL((k_ldl_pairdiag<T, false>), dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, w->Linv, w->D,
+                       V0, k, (int)w->nt, w->flag, wait_ready, need, b, y);
+  return BA_OK;
+}
+
+template <typename T>
+static int launch_pairtrsm(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *V1, T *b, hipStream_t st) {
+  const int m = (int)w->nt - k - 2;
+  if (m <= 0) return BA_OK;
+  ProfScope ps(p, PC_LDL_TRSM, st);
+  const T *y = w->D + w->nt * NB;
+  if (b)
+    hipLaunchKernelGGL((k_ldl_pairtrsm<T, true>), dim3(4 * m), dim3(256), PT_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, w->Linv,
+                       w->D, V0, V1, k, b, y);
+  else
+    hipLaunchKernelGGL((k_ldl_pairtrsm<T, false>), dim3(4 * m), dim3(256), PT_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, w->Linv,
+                       w->D, V0, V1, k, b, y);
   return BA_OK;
 }
 
@@ -986,24 +1295,43 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
     BA_HIP_CHECK(hipEventRecord(w->ev_top, st));
     BA_HIP_CHECK(hipStreamWaitEvent(w->hoist, w->ev_top, 0));
   }
+  // Fused pair schedule (see k_ldl_pairdiag): pair (k, k+1) is "fused" when its three leading tiles were factored by ONE
+  // hoisted workgroup beside the previous pair's trailing update; what then remains between two trailing updates is a single
+  // row-parallel kernel.  It pays while that update is long enough to hide the ~190 us of the hoisted workgroup (two
+  // diagonal tiles and two 128^3 products in sequence): FUSE_MIN_TILES tile rows.  Shorter updates keep round 1's schedule
+  // (one hoisted diagonal tile down to HOIST_MIN_TILES, strictly in order below that).  BA_LDL_FUSE=0 disables.
+  static const int fuse_min = [] { const char *e = getenv("BA_LDL_FUSE_MIN"); return e ? atoi(e) : 48; }();
+  static const bool fuse_off = [] { const char *e = getenv("BA_LDL_FUSE"); return e && e[0] == '0'; }();
+  auto fused = [&](int k) { return w->hoisting && !fuse_off && k >= 2 && k + 1 < nt && nt - k >= fuse_min; };
   launch_diag(p, w, 0, st);
   for (int k = 0, q = 0; k < nt; k += 2, q ^= 1) {
     T *V0 = Vs[q][0], *V1 = Vs[q][1];
-    const bool hoist = w->hoisting && (k + 2 < nt) && (nt - k - 2 >= HOIST_MIN_TILES);
-    if (hoist) {  // the next pair's first diagonal kernel: waits in place for ready[k+2]
+    const bool more = k + 2 < nt;
+    const bool next_fused = more && fused(k + 2);
+    const bool next_hoist1 = more && !next_fused && w->hoisting && (nt - k - 2 >= HOIST_MIN_TILES);
+    const int need = (k + 3 < nt) ? 3 : 1;
+    if (next_fused) {  // the next pair's leading tiles: waits in place for `need` tiles of this pair's trailing update
+      launch_pairdiag(p, w, k + 2, Vs[q ^ 1][0], d_b, w->hoist, w->ready + k + 2, need);
+      BA_HIP_CHECK(hipEventRecord(w->ev_chain, w->hoist));
+    } else if (next_hoist1) {  // the next pair's first diagonal tile only
       launch_diag(p, w, k + 2, w->hoist, w->ready + k + 2);
       BA_HIP_CHECK(hipEventRecord(w->ev_chain, w->hoist));
     }
-    launch_trsm(p, w, k, V0, d_b, st);  // diag(k) is done: first tile, hoisted, or the in-order branch below
-    if (k + 1 < nt) {
-      launch_col(p, w, k, V0, st);
-      launch_diag(p, w, k + 1, st);
-      launch_trsm(p, w, k + 1, V1, d_b, st);
+    if (fused(k)) {
+      launch_pairtrsm(p, w, k, V0, V1, d_b, st);
+    } else {
+      launch_trsm(p, w, k, V0, d_b, st);  // diag(k) is done: first tile, hoisted, or the in-order branch below
+      if (k + 1 < nt) {
+        launch_col(p, w, k, V0, st);
+        launch_diag(p, w, k + 1, st);
+        launch_trsm(p, w, k + 1, V1, d_b, st);
+      }
     }
-    if (k + 2 >= nt) break;
-    launch_pair(p, w, k, k + 2, V0, V1, st, hoist ? w->ready + k + 2 : nullptr);
-    if (hoist)
-      BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));  // join: Linv / D of tile k+2 are written
+    if (!more) break;
+    const bool hoisted = next_fused || next_hoist1;
+    launch_pair(p, w, k, k + 2, V0, V1, st, hoisted ? w->ready + k + 2 : nullptr, next_fused ? need : 1);
+    if (hoisted)
+      BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));  // join: the hoisted workgroup's outputs are written
     else
       launch_diag(p, w, k + 2, st);
   }

@@ -157,8 +157,10 @@ def test_unsorted_observations(ba, orc, small_prob, gpu_ok):
     m.close()
 
 
-@pytest.mark.parametrize("n", [5, 128, 200, 441, 700])
+@pytest.mark.parametrize("n", [5, 128, 200, 441, 700, 4480, 8100])
 def test_dense_ldl_vs_numpy(ba, n, gpu_ok):
+    """4480 (35 tile rows): the hoisted-diagonal schedule; 8100 (64 tile rows): the fused pair schedule (k_ldl_pairdiag
+    hoisted beside the trailing update, k_ldl_pairtrsm) for the first pairs, then the hoisted one, then in order."""
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n, n + 8))
     A = G @ G.T + 0.5 * np.eye(n)
@@ -638,6 +640,32 @@ def test_lm_step_f32_final_size(ba, gpu_ok):
     m.close()
 
 
+def test_dense_ldl_venice_size_all_schedules(ba, gpu_ok):
+    """n = 16 002 (Venice's reduced camera system, 126 tile rows): the fused pair schedule, round 1's hoisted-diagonal
+    schedule (BA_LDL_FUSE=0) and the strictly in-order one (BA_LDL_HOIST=0) must all solve the system (residual check:
+    numpy's own solve of a 2 GB matrix is not needed) and agree with each other to rounding."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import __graft_entry__ as ge; ba = ge.load_package(); "
+            "rng = np.random.default_rng(1); n = 16002; R = rng.standard_normal((n, n)); A = R + R.T; del R; "
+            "A[np.diag_indices(n)] += 4 * np.sqrt(n); b = rng.standard_normal(n); x, ms = ba._lib.dense_ldl_solve(A, b); "
+            "print('REL', np.linalg.norm(A @ x - b) / np.linalg.norm(b)); print('MS', ms); np.save(sys.argv[1], x)") % root
+    xs = {}
+    for tag, extra in (("fused", {}), ("hoist1", {"BA_LDL_FUSE": "0"}), ("inorder", {"BA_LDL_HOIST": "0"})):
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ba_ldl_{tag}_{os.getpid()}.npy")
+        r = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, env=dict(os.environ, **extra), timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rel = float([l for l in r.stdout.splitlines() if l.startswith("REL")][0].split()[1])
+        ms = float([l for l in r.stdout.splitlines() if l.startswith("MS")][0].split()[1])
+        print(f"{tag}: residual {rel:.2e}, factor {ms:.2f} ms")
+        assert rel < 1e-12, (tag, rel)
+        xs[tag] = np.load(out)
+        os.remove(out)
+    for tag in ("hoist1", "inorder"):
+        assert np.linalg.norm(xs[tag] - xs["fused"]) <= 1e-12 * np.linalg.norm(xs["fused"])
+
+
 def test_dense_ldl_hoisted_schedule_and_its_fallback(ba, gpu_ok):
     """n = 4480 (35 tile rows) is the smallest size that takes the hoisted-diagonal schedule of dense_ldl_factor.  Run it
     normally, then with every kernel launch serialised by the runtime (AMD_SERIALIZE_KERNEL=3, what a counter-collecting
@@ -647,12 +675,14 @@ def test_dense_ldl_hoisted_schedule_and_its_fallback(ba, gpu_ok):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import __graft_entry__ as ge; ba = ge.load_package(); "
-            "rng = np.random.default_rng(0); n = 4480; R = rng.standard_normal((n, n)); A = R + R.T; "
+            "rng = np.random.default_rng(0); n = int(sys.argv[1]); R = rng.standard_normal((n, n)); A = R + R.T; "
             "A[np.diag_indices(n)] += 4 * np.sqrt(n); b = rng.standard_normal(n); x, ms = ba._lib.dense_ldl_solve(A, b); "
             "print('REL', np.linalg.norm(A @ x - b) / np.linalg.norm(b))") % root
-    for extra in ({}, {"AMD_SERIALIZE_KERNEL": "3"}):
-        env = dict(os.environ, **extra)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
-        assert r.returncode == 0, r.stdout + r.stderr
-        rel = float([l for l in r.stdout.splitlines() if l.startswith("REL")][0].split()[1])
-        assert rel < 1e-12, (extra, rel)
+    # 4480: hoisted diagonal tile; 6800 (54 tile rows): the first pairs take the fused pair schedule (hoisted k_ldl_pairdiag)
+    for n in (4480, 6800):
+        for extra in ({}, {"AMD_SERIALIZE_KERNEL": "3"}):
+            env = dict(os.environ, **extra)
+            r = subprocess.run([sys.executable, "-c", code, str(n)], capture_output=True, text=True, env=env, timeout=300)
+            assert r.returncode == 0, r.stdout + r.stderr
+            rel = float([l for l in r.stdout.splitlines() if l.startswith("REL")][0].split()[1])
+            assert rel < 1e-12, (n, extra, rel)
