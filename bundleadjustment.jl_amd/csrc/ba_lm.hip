@@ -146,6 +146,11 @@ struct LMWorkFull : LMWork {
   DenseLDLT<float> ldl32;
   float *rhs32 = nullptr;
   bool have32 = false, last_f32 = false;
+  // facto_type = Float16 (src/lm.jl:165-169): set per solve; J_lin / r_lin / cr0: what the model value of the current step is
+  // evaluated on (the Float16-rounded scaled copies in that mode, J and r otherwise), see linear_step
+  bool f16 = false;
+  const double *J_lin = nullptr, *r_lin = nullptr;
+  double cr0 = 1.0;
   // eltype(x) = Float32 runs (BALNLPModel(file, Float32), src/BALNLPModels.jl:91): x, r and J are produced by the Float32
   // kernels and widened; every iterate is rounded to Float32.  Buffers allocated on first use.
   float *xf = nullptr, *rf = nullptr, *Jf = nullptr;
@@ -189,6 +194,16 @@ static int ensure_f32(LMWorkFull *w) {
   BA_CHECK(dense_ldl_alloc<float>(&w->ldl32, w->n, nullptr, w->ldl.world, w->ldl.rank));
   BA_HIP_CHECK(hipMalloc((void **)&w->rhs32, (size_t)w->npad * sizeof(float)));
   w->have32 = true;
+  return BA_OK;
+}
+
+static int ensure_f16(ba_problem *p, LMWorkFull *w) {
+  if (w->Jq) return BA_OK;
+  BA_CHECK(dmalloc(&w->jn2, w->nvar));
+  BA_CHECK(dmalloc(&w->dcol, w->nvar));
+  BA_CHECK(dmalloc(&w->damp, w->nvar));
+  BA_CHECK(dmalloc(&w->Jq, 24 * p->nobs));
+  BA_CHECK(dmalloc(&w->rq, w->nequ));
   return BA_OK;
 }
 
@@ -246,7 +261,7 @@ void lm_free(ba_problem *p) {
   if (w->xf) (void)hipFree(w->xf);
   if (w->rf) (void)hipFree(w->rf);
   if (w->Jf) (void)hipFree(w->Jf);
-  void *ptrs[] = {w->x, w->x_trial, w->delta, w->r, w->r_trial, w->J, w->Hpp, w->gp, w->Uinv, w->u, w->Hcc,
+  void *ptrs[] = {w->jn2, w->dcol, w->damp, w->Jq, w->rq, w->x, w->x_trial, w->delta, w->r, w->r_trial, w->J, w->Hpp, w->gp, w->Uinv, w->u, w->Hcc,
                   w->partial, w->colscale, w->Yobs, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
                   w->tasks.task_a, w->tasks.task_b, w->s.own_red ? w->s.red : nullptr};
   for (void *q : ptrs)
@@ -318,6 +333,7 @@ static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too
   // adjacent in the reduce buffer: one all-reduce
   BA_CHECK(launch_hcc_diag(p, w->Hcc, w->hdiag, st));
   BA_CHECK(comm_sum(p, w, w->s.off_gc, 2 * w->npad + SH_LIN_COUNT, st));
+  if (w->f16) BA_CHECK(launch_col_sq(p, w->Hpp, w->hdiag, w->jn2, st));  // |J_j|^2 before the blocks are overwritten by scaled ones
   BA_CHECK(launch_sumsq(p, w->n, w->gc, w->partial, w->s.scal_rep, RP_GC, st));
   BA_CHECK(launch_sumsq(p, w->n, w->x + 3 * p->npnts, w->partial, w->s.scal_rep, RP_X_C, st));
   return BA_OK;
@@ -336,11 +352,27 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   // d_lambda: the damping is read from device memory (recorded launches); `lambda` is then the multiplier 1
   // every rank holds partial Hcc / Schur sums; the lambda I of the camera block is added by rank 0 only
   const double lam_diag = (p->rank == 0) ? lambda : 0.0;
-  BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, d_lambda));
-  BA_CHECK(launch_schur_blocks(p, &w->tasks, w->J, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
-                               p->rank == 0 ? w->npad : w->n, st, d_lambda));
+  const double *Jl = w->J, *rl = w->r, *damp = nullptr;
+  constexpr double MU16 = 0.1 * 6.55e4;  // lma_aux.jl:44-48
+  if (w->f16) {
+    // facto_type = Float16: columns scaled by their norms, entries and right-hand side rounded to Float16 (k_f16_cols); the
+    // normal-equation blocks are rebuilt from the rounded copies, the damping is per column
+    BA_CHECK(launch_f16_scale(p, lambda, MU16, w->jn2, w->J, w->r, w->dcol, w->damp, w->Jq, w->rq, st));
+    BA_CHECK(launch_point_blocks(p, w->Jq, w->rq, w->Hpp, w->gp, st));
+    BA_CHECK(launch_cam_blocks(p, w->Jq, w->rq, w->Hcc, w->gc, st));
+    Jl = w->Jq;
+    rl = w->rq;
+    damp = w->damp;
+    normalize = 0;  // lm.jl:156,232: no column scaling of J in the Float16 branch
+  }
+  w->J_lin = Jl;
+  w->r_lin = rl;
+  w->cr0 = w->f16 ? 1.0 / MU16 : 1.0;
+  BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, d_lambda, damp));
+  BA_CHECK(launch_schur_blocks(p, &w->tasks, Jl, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
+                               p->rank == 0 ? w->npad : w->n, st, d_lambda, damp));
   BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
-  BA_CHECK(launch_schur_rhs(p, w->J, w->r, w->u, w->rhs, st));
+  BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st));
   BA_CHECK(reduce_camera_system(p, w, st));
   const bool dist = dist_factor_on(p);
   if (normalize != 0) {  // :J / :A column scaling of the camera system from the GLOBAL diagonal (refresh_linearisation)
@@ -371,13 +403,15 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   double *dc = w->delta + 3 * p->npnts;
   if (normalize != 0) BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));  // dc = D^-1 dc'
   BA_HIP_CHECK(hipMemcpyAsync(dc, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->u, dc, w->delta, st));
+  BA_CHECK(launch_backsub(p, Jl, w->Uinv, w->u, dc, w->delta, st));
+  if (w->f16) BA_CHECK(launch_scale_scalar(p, w->nvar, w->delta, 1.0 / MU16, st));  // the right-hand side was -Jh' r / mu
   return BA_OK;
 }
 
 // cr: the model value is |J delta + cr r|^2 (1 outside the line search)
-static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st, double cr = 1.0) {
-  BA_CHECK(launch_model_sq(p, w->J, w->r, w->delta, w->partial, w->scal, SH_MODEL, st, cr));
+static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st, double cr = -1.0) {
+  if (cr < 0) cr = w->cr0;
+  BA_CHECK(launch_model_sq(p, w->J_lin, w->r_lin, w->delta, w->partial, w->scal, SH_MODEL, st, cr));
   BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->delta, w->partial, w->scal, SH_DELTA_P, st));
   BA_CHECK(launch_sumsq(p, w->n, w->delta + 3 * p->npnts, w->partial, w->s.scal_rep, RP_DELTA_C, st));
   return BA_OK;
@@ -414,7 +448,7 @@ static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 
 // ---- recorded launch sequences ------------------------------------------------------------------------------------------
 static bool graphs_allowed(ba_problem *p, LMWorkFull *w) {
-  if (w->g_off || p->prof_on || p->comm.active()) return false;  // per-kernel events / communicator
+  if (w->g_off || p->prof_on || p->comm.active() || w->f16) return false;  // per-kernel events / communicator / Float16 path
   // the hoisted-diagonal schedule of large factorisations has a kernel wait for a flag raised by a kernel running
   // beside it: only with real streams is that concurrency certain (and the graphs gain nothing at that size)
   if (w->ldl.nt >= 34) return false;  // = HOIST_MIN_TILES + 2 of dense_ldl_factor (above its HOIST_MAX_TILES graphs gain nothing either)
@@ -534,6 +568,7 @@ static int lm_step_impl(ba_problem *p, const double *x, double lambda, double *d
   LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
   hipStream_t st = p->stream;
   BA_HIP_CHECK(hipMemcpyAsync(w->x, x, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
+  w->f16 = false;
   BA_CHECK(refresh_linearisation(p, w, true, st));
   BA_CHECK(linear_step(p, w, lambda, 0, st, facto_f32));
   {  // same fallback as the LM loop: a hoisted diagonal kernel that gave up -> in-order schedule, redo the step
@@ -579,8 +614,12 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     ba_set_error("ba_lm_solve: facto must be 0 (:LDL) or 1 (:QR)");
     return BA_ERR_ARG;
   }
-  if (o->facto_type < 0 || o->facto_type > 1) {
-    ba_set_error("ba_lm_solve: facto_type must be 0 (eltype(x)) or 1 (Float32); the Float16 path of src/lm.jl:165-169 is not provided");
+  if (o->facto_type < 0 || o->facto_type > 2) {
+    ba_set_error("ba_lm_solve: facto_type must be 0 (eltype(x)), 1 (Float32) or 2 (Float16)");
+    return BA_ERR_ARG;
+  }
+  if (o->facto_type == 2 && (o->variant != 1 || o->facto != 0 || p->comm.active())) {
+    ba_set_error("ba_lm_solve: facto_type = Float16 exists in lm.jl's :LDL branch only (src/lm.jl:92-95,165-169), one GPU");
     return BA_ERR_ARG;
   }
   if (o->normalize < 0 || o->normalize > 2) {
@@ -596,6 +635,9 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   // defaults: src/lm.jl:20-26 / src/LevenbergMarquardt.jl:21-26
   const bool xf32 = o->x_f32 != 0;  // eltype(x) = Float32: eps(T)-derived defaults, Float32 iterates and evaluations
   if (xf32) BA_CHECK(ensure_xf32(p, w));
+  w->f16 = V && o->facto_type == 2;
+  if (w->f16) BA_CHECK(ensure_f16(p, w));
+  const bool facto_f32 = V && o->facto_type >= 1;  // Float16 inputs are eliminated and factored in Float32
   const double eps = xf32 ? 1.1920928955078125e-07 : 2.220446049250313e-16, sq = std::sqrt(eps), cbr = std::pow(eps, 1.0 / 3.0);
   const double restol = o->restol >= 0 ? o->restol : (V ? cbr : 100 * sq);
   const double satol = o->satol >= 0 ? o->satol : sq, srtol = o->srtol >= 0 ? o->srtol : sq;
@@ -641,7 +683,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   while (!(small_step || first_order || small_residual || small_obj_change || tired || fail2)) {
     if (V) iter++;                                                                           // lm.jl:127
     if (!V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);  // LevenbergMarquardt.jl:143-147
-    if ((rc = trial_step(p, w, lambda, o->normalize, V && o->facto_type == 1, xf32, st)) != BA_OK) break;  // lm.jl:154-254
+    if ((rc = trial_step(p, w, lambda, o->normalize, facto_f32, xf32, st)) != BA_OK) break;  // lm.jl:154-254
     stats->n_factor++;
     stats->n_residual++;
     if (*w->h_flag == 2) {
@@ -665,7 +707,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
       pred = obj - dr2;
       ared = obj - obj_suiv;
       step_accepted = ared >= 1e-4 * pred;  // lm.jl:257-259
-      double c_r = 1.0;  // delta_r = -(J delta + c_r r)
+      double c_r = w->cr0;  // delta_r = -(J delta + c_r r)   (1; 1/mu in the Float16 branch)
       while (linesearch && !step_accepted && ntimes < 4) {  // lm.jl:264-295
         // delta /= delta_d ; delta_r = (delta_r - r)/delta_d (lm.jl:277): with delta_r = -(J delta + c r) the update is
         // c <- (c + 1)/delta_d, which stays 1 only for the default delta_d = 2 (the reference's comment at lm.jl:275-276

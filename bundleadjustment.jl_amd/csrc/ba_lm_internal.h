@@ -26,6 +26,8 @@ struct LMWork {
   double *hdiag = nullptr;               // npad: diag of the camera block of J'J summed over all ranks (column scalings)
   double *rhs = nullptr;                 // npad
   double *colscale = nullptr;            // nvar (normalize != None)
+  // facto_type = Float16: |J_j|^2, column norms, damping vector (nvar each), quantised J (24/obs) and r; allocated on first use
+  double *jn2 = nullptr, *dcol = nullptr, *damp = nullptr, *Jq = nullptr, *rq = nullptr;
   double *partial = nullptr;             // RED_BLOCKS
   double *scal = nullptr;                // SC_COUNT device scalars
   double *h_scal = nullptr;              // pinned host mirror
@@ -35,10 +37,14 @@ struct LMWork {
 
 // d_lambda (optional device scalar): the damping used is lambda * d_lambda[0] (hipGraph replays, ba_lm.hip)
 int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const double *d_gp, double *d_Uinv,
-                      double *d_u, hipStream_t st, const double *d_lambda = nullptr);
+                      double *d_u, hipStream_t st, const double *d_lambda = nullptr, const double *d_damp = nullptr);
 int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
                         const double *d_Hcc, double lambda, double *d_S, const int64_t *d_col_off, int64_t n, int64_t npad,
-                        hipStream_t st, const double *d_lambda = nullptr);
+                        hipStream_t st, const double *d_lambda = nullptr, const double *d_damp = nullptr);
+// facto_type = Float16 (ba_normal_kernels.hip, k_f16_cols): |J_j|^2 of every column; column scaling + Float16 rounding
+int launch_col_sq(ba_problem *p, const double *d_Hpp, const double *d_hdiag, double *d_jn2, hipStream_t st);
+int launch_f16_scale(ba_problem *p, double lambda, double mu, const double *d_jn2, const double *d_J, const double *d_r,
+                     double *d_dcol, double *d_damp, double *d_Jq, double *d_rq, hipStream_t st);
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
                      hipStream_t st);
 int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,

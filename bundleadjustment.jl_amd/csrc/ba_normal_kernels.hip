@@ -13,6 +13,8 @@
 // All sums are deterministic: point-side sums run over the point-sorted observation list (one lane per
 // point), camera-side sums over the camera-sorted list (one workgroup per camera, fixed tree), the Schur
 // blocks over a (camera_a, camera_b)-sorted task list (one wave per 9x9 block).  No float atomics.
+#include <hip/hip_fp16.h>
+
 #include "ba_internal.h"
 #include "ba_lm_internal.h"
 
@@ -123,14 +125,17 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_
 // ---- per point: U^-1 = (Hpp + lambda I)^-1 (6, symmetric) and u = U^-1 gp -------------------------------------
 // lam_dev (here and below): when non-null the damping is lambda * lam_dev[0] -- a launch recorded in a hipGraph keeps
 // its arguments, so the replayed LM iteration reads the current damping from device memory.
+// damp (Float16 path only): a per-variable damping vector in the layout of x replaces lambda I (see k_f16_cols).
 __global__ __launch_bounds__(BLK) void k_schur_prep(int64_t npnts, double lambda, const double *__restrict__ lam_dev,
                                                      const double *__restrict__ Hpp, const double *__restrict__ gp,
-                                                     double *__restrict__ Uinv, double *__restrict__ u) {
+                                                     double *__restrict__ Uinv, double *__restrict__ u,
+                                                     const double *__restrict__ damp) {
   int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x;
   if (p >= npnts) return;
   if (lam_dev) lambda *= lam_dev[0];
   const double *h = Hpp + 6 * p;
-  double a = h[0] + lambda, b = h[1], c = h[2], d = h[3] + lambda, e = h[4], f = h[5] + lambda;
+  const double l0 = damp ? damp[3 * p] : lambda, l1 = damp ? damp[3 * p + 1] : lambda, l2 = damp ? damp[3 * p + 2] : lambda;
+  double a = h[0] + l0, b = h[1], c = h[2], d = h[3] + l1, e = h[4], f = h[5] + l2;
   // cofactors of the symmetric 3x3 [[a b c],[b d e],[c e f]]
   double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
   double c11 = a * f - c * c, c12 = b * c - a * e, c22 = a * d - b * b;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
                                                        const double *__restrict__ J, const double *__restrict__ Y,
                                                        const double *__restrict__ Hcc, double lambda,
                                                        const double *__restrict__ lam_dev, double *__restrict__ S,
-                                                       const int64_t *__restrict__ co) {
+                                                       const int64_t *__restrict__ co, const double *__restrict__ damp_c) {
   __shared__ double stage[BLK / 64][2][48];
   if (lam_dev) lambda *= lam_dev[0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
         double v = -acc[g];
         if (ca == cb) {
           int hi = i > j ? i : j, lo = i > j ? j : i;
-          v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i == j ? lambda : 0.0);
+          v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i == j ? (damp_c ? damp_c[9 * (int64_t)ca + i] : lambda) : 0.0);
         }
         if (r0 + i >= c0 + j) s_store(S, co, r0 + i, c0 + j, v);
       }
@@ -306,6 +311,59 @@ __global__ __launch_bounds__(BLK) void k_scale_S(int64_t n, int64_t nt, const do
 __global__ void k_pad_diag(int64_t n, int64_t npad, double *S, const int64_t *co) {
   int64_t i = n + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < npad) s_store(S, co, i, i, 1.0);
+}
+
+// ---- facto_type = Float16 (src/lm.jl:165-169, src/lma_aux.jl:30-52,90-95) ------------------------------------------------
+// The reference scales every column j of the upper triangle of K = [[I J];[J' -lambda I]] by its 2-norm D_j, multiplies by
+// mu = 0.1 * 65500, rounds to Float16 and factors THAT matrix in Float16; the right-hand side is [-r; 0] rounded to Float16
+// and the solution's variable block is taken as the step without any back-scaling.  D_j = 1 on the residual rows and
+// sqrt(|J_j|^2 + lambda^2) on the variable columns, so in exact arithmetic the step is
+//     (Jh' Jh + Lh) y = -Jh' r / mu,   Jh = J D^-1,  Lh = diag(lambda / D_j),   delta = y,   delta_r = -r / mu - Jh y.
+// The device keeps what the reference's inputs lose -- Jh, Lh and r go through Float16 -- and then eliminates and factors in
+// Float32 (the reduced camera system), instead of carrying Float16 through ~10^5 pivots.
+__device__ inline double round_f16(double v) { return (double)__half2float(__float2half_rn((float)v)); }
+
+// column norms and damping of the variable columns: dcol[j] = sqrt(jn2[j] + lambda^2), damp[j] = f16(mu lambda / dcol[j]) / mu
+__global__ __launch_bounds__(BLK) void k_f16_cols(int64_t nvar, const double *__restrict__ jn2, double lambda, double mu,
+                                                   double *__restrict__ dcol, double *__restrict__ damp) {
+  int64_t j = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (j >= nvar) return;
+  const double d = sqrt(jn2[j] + lambda * lambda);
+  dcol[j] = d;
+  damp[j] = round_f16(mu * (lambda / d)) / mu;
+}
+
+// |J_j|^2 of every column from the diagonals of the normal-equation blocks (layout of x)
+__global__ __launch_bounds__(BLK) void k_col_sq(int64_t npnts, int64_t ncams, const double *__restrict__ Hpp,
+                                                 const double *__restrict__ hdiag, double *__restrict__ jn2) {
+  int64_t j = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (j < 3 * npnts) {
+    const int c = (int)(j % 3);
+    jn2[j] = Hpp[6 * (j / 3) + (c == 0 ? 0 : (c == 1 ? 3 : 5))];
+  } else if (j < 3 * npnts + 9 * ncams) {
+    jn2[j] = hdiag[j - 3 * npnts];
+  }
+}
+
+// Jq = f16(mu J / D) / mu, rq = f16(r): one lane per observation
+__global__ __launch_bounds__(BLK) void k_f16_quantize(int64_t nobs, int64_t npnts, const int *__restrict__ cam0,
+                                                       const int *__restrict__ pnt0, const double *__restrict__ J,
+                                                       const double *__restrict__ r, const double *__restrict__ dcol, double mu,
+                                                       double *__restrict__ Jq, double *__restrict__ rq) {
+  int64_t o = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (o >= nobs) return;
+  const double *dp = dcol + 3 * (int64_t)pnt0[o], *dc = dcol + 3 * npnts + 9 * (int64_t)cam0[o];
+  const double *Jo = J + 24 * o;
+  double *Qo = Jq + 24 * o;
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) Qo[12 * a + c] = round_f16(mu * (Jo[12 * a + c] / dp[c])) / mu;
+#pragma unroll
+    for (int c = 0; c < 9; c++) Qo[12 * a + 3 + c] = round_f16(mu * (Jo[12 * a + 3 + c] / dc[c])) / mu;
+  }
+  rq[2 * o] = round_f16(r[2 * o]);
+  rq[2 * o + 1] = round_f16(r[2 * o + 1]);
 }
 
 // ---- back-substitution of the points: dp = -(u_p + U^-1 sum_a A_a' (B_a dc[c_a])) ----------------------------------
@@ -437,18 +495,18 @@ int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, doubl
 }
 
 int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const double *d_gp, double *d_Uinv,
-                      double *d_u, hipStream_t st, const double *d_lambda) {
+                      double *d_u, hipStream_t st, const double *d_lambda, const double *d_damp) {
   if (p->npnts == 0) return BA_OK;
   ProfScope ps(p, PC_SCHUR_PREP, st);
   hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, lambda, d_lambda, d_Hpp,
-                     d_gp, d_Uinv, d_u);
+                     d_gp, d_Uinv, d_u, d_damp);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
 
 int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
                         const double *d_Hcc, double lambda, double *d_S, const int64_t *d_col_off, int64_t n, int64_t npad,
-                        hipStream_t st, const double *d_lambda) {
+                        hipStream_t st, const double *d_lambda, const double *d_damp) {
   ProfScope ps(p, PC_SCHUR_S, st);
   BA_HIP_CHECK(hipMemsetAsync(d_S, 0, (size_t)dense_ldl_tiles_doubles(n) * sizeof(double), st));
   if (p->nobs > 0)
@@ -457,7 +515,8 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
     int64_t nb = (T->nkeys + BLK / 64 - 1) / (BLK / 64);
     if (nb > (int64_t)1 << 22) nb = (int64_t)1 << 22;  // 2^22 blocks x 256 lanes = 2^30 work-items
     hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nb), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
-                       T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, d_S, d_col_off);
+                       T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, d_S, d_col_off,
+                       d_damp ? d_damp + 3 * p->npnts : (const double *)nullptr);
   }
   if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S, d_col_off);
   BA_HIP_CHECK(hipGetLastError());
@@ -551,6 +610,26 @@ int launch_scale_scalar(ba_problem *p, int64_t n, double *d_v, double alpha, hip
 int launch_scale_vec(ba_problem *p, int64_t n, const double *d_s, double *d_v, int divide, hipStream_t st) {
   if (n == 0) return BA_OK;
   hipLaunchKernelGGL(k_scale_vec, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, d_s, d_v, divide);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+// ---- facto_type = Float16 helpers (see k_f16_cols) ---------------------------------------------------------------------
+int launch_col_sq(ba_problem *p, const double *d_Hpp, const double *d_hdiag, double *d_jn2, hipStream_t st) {
+  const int64_t nvar = 3 * p->npnts + 9 * p->ncams;
+  if (nvar == 0) return BA_OK;
+  hipLaunchKernelGGL(k_col_sq, dim3(grid_for(nvar, BLK)), dim3(BLK), 0, st, p->npnts, p->ncams, d_Hpp, d_hdiag, d_jn2);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_f16_scale(ba_problem *p, double lambda, double mu, const double *d_jn2, const double *d_J, const double *d_r,
+                     double *d_dcol, double *d_damp, double *d_Jq, double *d_rq, hipStream_t st) {
+  const int64_t nvar = 3 * p->npnts + 9 * p->ncams;
+  if (nvar > 0) hipLaunchKernelGGL(k_f16_cols, dim3(grid_for(nvar, BLK)), dim3(BLK), 0, st, nvar, d_jn2, lambda, mu, d_dcol, d_damp);
+  if (p->nobs > 0)
+    hipLaunchKernelGGL(k_f16_quantize, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_J,
+                       d_r, d_dcol, mu, d_Jq, d_rq);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }

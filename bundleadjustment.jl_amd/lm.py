@@ -72,17 +72,21 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
     x0 = np.array(nlp.meta.x0 if x is None else x, dtype=np.float64, copy=True)
     if x0.shape != (nlp.meta.nvar,):
         raise ValueError("x has the wrong length")
-    f32 = (facto_type is None and xf32 and variant == 1) or \
-        (facto_type is not None and np.dtype(facto_type) == np.float32)
-    if facto_type is not None and np.dtype(facto_type) not in (np.dtype(np.float64), np.dtype(np.float32)):
-        raise NotImplementedError("facto_type must be Float64 or Float32 (the Float16 path of lm.jl:165-169 is experimental "
-                                  "in the reference and not provided)")
+    if facto_type is not None and np.dtype(facto_type) not in (np.dtype(np.float64), np.dtype(np.float32), np.dtype(np.float16)):
+        raise TypeError("facto_type must be Float64, Float32 or Float16")
+    # ba_lm_opts.facto_type: 0 = eltype(x), 1 = Float32, 2 = Float16 (src/lm.jl:165-173)
+    if facto_type is None:
+        ft = 1 if (xf32 and variant == 1) else 0  # facto_type defaults to eltype(x) (lm.jl:20)
+    else:
+        ft = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.float16): 2}[np.dtype(facto_type)]
+    if ft == 2 and _FACTO[facto] != 0:
+        raise ValueError("facto_type = Float16 exists in the :LDL branch only (src/lm.jl:92-95)")
 
     def d(v):
         return -1.0 if v is None else float(v)
 
     o = _lib.LMOpts(variant=variant, facto=_FACTO[facto], normalize=_NORM[normalize], linesearch=int(bool(linesearch)),
-                    facto_type=int(f32), ite_max=-1 if ite_max is None else int(ite_max), verbose=int(verbose), x_f32=int(xf32),
+                    facto_type=ft, ite_max=-1 if ite_max is None else int(ite_max), verbose=int(verbose), x_f32=int(xf32),
                     restol=d(restol), satol=d(satol), srtol=d(srtol), oatol=d(oatol), ortol=d(ortol), atol=d(atol),
                     rtol=d(rtol), nu_d=d(nu_d), nu_m=d(nu_m), lam=d(lam), delta_d=d(delta_d), max_time=d(max_time))
     st = _lib.LMStats()

@@ -121,8 +121,11 @@ typedef struct ba_lm_opts {
                    *    while :LDL uses the recursion of src/lm.jl:277 (they differ for delta_d != 2) */
   int normalize;  /* 0 :None, 1 :J, 2 :A  (src/lma_aux.jl:102-178) */
   int linesearch; /* lm.jl only, src/lm.jl:264-295 */
-  int facto_type; /* lm.jl only, `facto_type` keyword: 0 = eltype(x) (Float64, or Float32 for a Float32 model), 1 = Float32
-                   *    (src/lm.jl:170-173, src/diffprecsions.jl:39-41), 2 = Float16 (src/lm.jl:165-169, src/lma_aux.jl:30-95) */
+  int facto_type; /* lm.jl only, `facto_type` keyword: 0 = Float64 (the default for a Float64 model), 1 = Float32
+                   *    (src/lm.jl:170-173, src/diffprecsions.jl:39-41; the default for a Float32 model), 2 = Float16
+                   *    (src/lm.jl:165-169, src/lma_aux.jl:30-95: columns of K scaled by their norms and by mu = 6550,
+                   *    entries and right-hand side rounded to Float16, step taken unscaled -- the device rounds the same
+                   *    inputs and then eliminates / factors in Float32; :LDL only, one GPU) */
   int ite_max;    /* <0: default (200 / 100) */
   int verbose;    /* 1: print the reference's log columns to stderr */
   int x_f32;      /* 1: eltype(x) = Float32 (a BALNLPModel(file, Float32) run): iterates rounded to Float32, residual and

@@ -190,6 +190,7 @@ def lm_solve(ncams, npnts, cam_idx1, pnt_idx1, pt2d, x0, variant=1, normalize=0,
     """Levenberg_Marquardt(...) of lm.jl (variant=1) or LevenbergMarquardt.jl (variant=0); facto="QR": the :QR branch of
     lm.jl with a dense Householder QR (small problems only: the matrix is densified)."""
     nobs = len(cam_idx1)
+    # facto_f32: False/0 Float64, True/1 Float32, 2 Float16 (emulated: Float32 operation + rounding to binary16, as Julia)
     o = LMOpts(variant=variant, normalize=normalize, linesearch=int(linesearch), facto_f32=int(facto_f32),
                ite_max=ite_max, restol=tols.get("restol", -1.0), satol=tols.get("satol", -1.0),
                srtol=tols.get("srtol", -1.0), oatol=tols.get("oatol", -1.0), ortol=tols.get("ortol", -1.0),

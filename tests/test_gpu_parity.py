@@ -423,6 +423,60 @@ def test_lm_facto_f32(ba, orc, small_prob, gpu_ok):
     m.close()
 
 
+def test_lm_facto_f16_and_two_stage_restart(ba, orc, small_prob, gpu_ok):
+    """facto_type = Float16 (src/lm.jl:92-95,165-169; normalize_F16! / normalize_vect!, src/lma_aux.jl:30-52,90-95) and the
+    two-stage scheme of src/benchmark_diffprec.jl:38-72: a Float16 stage with loose tolerances, then a restart in Float64
+    from its solution (`x=`).  The oracle runs the reference's algorithm in emulated Float16 arithmetic (Float32 operation,
+    result rounded to binary16, as Julia does); the device rounds the same inputs to Float16 and then works in Float32.
+    Float16-level tolerance: per step |delta| to 2 %, objective to 1 % over the first rows, 10 % later (rounding noise of
+    ~10^5 Float16 pivots in the oracle accumulates); the statuses the reference's own Float16 runs end with are allowed
+    (benchmark/diffprec/lm_diffprec_F1632_64.log:55,1610: step too small, unhandled exception)."""
+    p = small_prob
+    x0 = _hard_start(p, 0.1, 0.02, 3)
+    tol16 = dict(oatol=1e-2, ortol=1e-2, atol=1e-2, rtol=1e-1, satol=1e-5, srtol=1e-5, restol=1e-5)  # benchmark_diffprec.jl:46
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    fr = ba.FeasibilityResidual(m)
+    st16 = ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False, x=x0, facto_type=np.float16, ite_max=30, **tol16)
+    rc, x_ref, st_ref, log_ref = orc.lm_solve(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], x0, variant=1,
+                                              facto_f32=2, ite_max=30, **tol16)
+    assert rc == 0
+    print("device Float16 stage:", st16.iter, st16.status, st16.objective, "oracle:", st_ref.iter, orc.STATUS[st_ref.status],
+          st_ref.objective)
+    log = np.array([r[:7] + (float(r[7]),) for r in st16.log])
+    n = min(len(log), len(log_ref))
+    assert n >= 4
+    print("f  device", log[:n, 1], "\nf  oracle", log_ref[:n, 1], "\n|d| device", log[:n, 5], "\n|d| oracle", log_ref[:n, 5])
+    k = min(n, 5)
+    assert [bool(v) for v in log[:k, 7]] == [bool(v) for v in log_ref[:k, 7]]
+    assert np.allclose(log[:k, 4], log_ref[:k, 4], rtol=1e-9)   # lambda: same decisions
+    assert np.allclose(log[:k, 5], log_ref[:k, 5], rtol=2e-2)   # |delta|
+    assert np.allclose(log[:k, 1], log_ref[:k, 1], rtol=1e-2)   # objective
+    assert np.allclose(log[:n, 1], log_ref[:n, 1], rtol=1e-1)
+    assert st16.status in ("small_step", "acceptable", "first_order", "exception", "max_iter")
+    f0 = 0.5 * float(np.sum(m.cons(x0) ** 2))
+    assert st16.objective < 0.5 * f0  # the Float16 stage makes real progress ...
+    st64 = ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False, x=x0)
+    assert st16.objective > 2 * st64.objective  # ... but stops far from the minimum (its steps are scaled by D_j / mu)
+    # stage 2: restart in Float64 from the Float16 solution (benchmark_diffprec.jl:52)
+    st2 = ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False, x=st16.solution)
+    print("restart:", st2.iter, st2.status, st2.objective, " direct Float64:", st64.iter, st64.status, st64.objective)
+    assert st2.status in ("first_order", "acceptable", "small_residual", "small_step")
+    assert abs(st2.objective - st64.objective) <= 1e-4 * st64.objective
+    # the reference's actual combination: a Float32 model with facto_type = Float16, restart with facto_type = Float32
+    arr = list(ba.synthetic.as_arrays(p))
+    arr32 = [arr[0], arr[1], arr[2].astype(np.float32), arr[3].astype(np.float32)] + arr[4:]
+    m32 = ba.BALNLPModel(arrays=tuple(arr32), T=np.float32)
+    s1 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), "LDL", "Metis", "None", False, x=x0.astype(np.float32),
+                                facto_type=np.float16, ite_max=30, **tol16)
+    s2 = ba.Levenberg_Marquardt(fr, "LDL", "Metis", "None", False, x=s1.solution.astype(np.float64), facto_type=np.float32)
+    print("Float32 model, Float16 stage:", s1.iter, s1.status, s1.objective, "-> Float32/64 stage:", s2.iter, s2.status, s2.objective)
+    assert s1.objective < 0.5 * f0 and abs(s2.objective - st64.objective) <= 1e-3 * st64.objective
+    with pytest.raises(ValueError):  # Float16 exists in the :LDL branch only (src/lm.jl:92-95)
+        ba.Levenberg_Marquardt(fr, "QR", "AMD", "None", False, x=x0, facto_type=np.float16)
+    m32.close()
+    m.close()
+
+
 def test_lm_float32_model(ba, small_prob, gpu_ok):
     """BALNLPModel(file, Float32) through Levenberg_Marquardt (eltype(x) = Float32, facto_type defaults to Float32,
     eps(Float32) tolerances -- lm.jl:20-26).  No reference fixture pins a Float32 run (parity unpinned); checked here:
