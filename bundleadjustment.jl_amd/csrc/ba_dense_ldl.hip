@@ -461,6 +461,68 @@ __device__ inline void tile_gemm_abt_priv(const T *__restrict__ A0, const T *__r
   }
 }
 
+// LDS-DMA variant of the wave-private product (Float64): the operand chunks go global -> LDS directly
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write, no wait between a load and its LDS write), chunks of 8, two LDS
+// buffers per wave (16 KB per wave, 64 KB per workgroup); the next chunk's 8 pieces are in flight during the MFMAs and the
+// wave waits with vmcnt only.  A piece lands at base + lane * 16 bytes, so rows are unpadded (64 B): the 16-byte columns are
+// XOR-swizzled with the row ((row >> 2) & 3), which keeps the MFMA operand reads at two dwords per bank.  Same products in
+// the same order as tile_gemm_abt_priv (bit-identical accumulators; tools/bench_mfma_probe.py modes 3 / 5 compare their
+// checksums).  Probe, nonzero operands, steady state: 68.6-68.7 TFLOP/s against 66.1-66.2 for the register-staged loop.
+constexpr int DKC = 8;
+constexpr size_t GEMM_DMA_LDS_ELEMS = (size_t)4 * 2 * 2 * 64 * DKC;
+__device__ inline void tile_gemm_abt_dma(const double *__restrict__ A0, const double *__restrict__ B0,
+                                         const double *__restrict__ A1, const double *__restrict__ B1, double *lds,
+                                         RT<double>::v4 acc[4][4]) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  const int fr = lane & 15, fk = lane >> 4;
+  double *wbase = lds + wv * (2 * 2 * 64 * DKC);  // [buffer][A | B][64 rows][8]
+  const int prow = lane >> 2, pc2 = lane & 3;     // a piece: 16 rows x 64 B; this lane's row and 16-byte slot inside it
+  int off[2][4];  // operand read offsets inside a 64 x 8 slice: row r, element k -> r*8 + (((k>>1) ^ ((r>>2)&3)) << 1) + (k&1)
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int r = 16 * m + fr, k = 4 * kk + fk;
+      off[kk][m] = r * DKC + (((k >> 1) ^ ((r >> 2) & 3)) << 1) + (k & 1);
+    }
+  constexpr int NCHK = 2 * NB / DKC, HALF = NB / DKC;
+  auto issue = [&](int ch) {  // 8 DMA pieces: chunk ch of A and B into buffer ch & 1
+    double *dst = wbase + (ch & 1) * (2 * 64 * DKC);
+    const double *A = (ch < HALF ? A0 : A1) + (size_t)wr * NB, *B = (ch < HALF ? B0 : B1) + (size_t)wc * NB;
+    const int k0 = (ch & (HALF - 1)) * DKC;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = 16 * q + prow;
+      const int c2 = pc2 ^ ((r >> 2) & 3);
+      __builtin_amdgcn_global_load_lds(A + (size_t)r * NB + k0 + 2 * c2, dst + q * 16 * DKC, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(B + (size_t)r * NB + k0 + 2 * c2, dst + 64 * DKC + q * 16 * DKC, 16, 0, 0);
+    }
+  };
+  issue(0);
+  for (int ch = 0; ch < NCHK; ch++) {
+    if (ch + 1 < NCHK) {
+      issue(ch + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk ch has landed; chunk ch + 1 (8 pieces) may still be in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const double *cA = wbase + (ch & 1) * (2 * 64 * DKC), *cB = cA + 64 * DKC;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) af[m] = cA[off[kk][m]];
+#pragma unroll
+      for (int n = 0; n < 4; n++) bf[n] = cB[off[kk][n]];
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = RT<double>::mfma(af[m], bf[n], acc[m][n]);
+    }
+  }
+}
+
 // ---- row-split panel kernels (latency path) ----------------------------------------------------------------------------
 // The panel solve and the one-column update have only (nt-k-1) tiles of work: one workgroup per tile leaves most CUs
 // idle and takes a full 128x128x128 product (27-33 us) on the critical path of every panel.  Here a workgroup owns
@@ -930,7 +992,10 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
 #pragma unroll
     for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
   const int io = (DBG & 2) ? base : i, jo = (DBG & 2) ? base : j;
-  if (!(DBG & 8))
+  if constexpr ((DBG & 16) != 0 && sizeof(T) == 8)
+    tile_gemm_abt_dma(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                      S + tix(co, jo, k + 1) * NB * NB, lds, acc);
+  else if (!(DBG & 8))
     tile_gemm_abt_priv<T, 2>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
                           S + tix(co, jo, k + 1) * NB * NB, lds, acc);
   else

@@ -11,6 +11,7 @@
 //
 // One device->host copy of a handful of scalars per iteration drives the accept/reject logic, as the reference's
 // norm() calls do.  As in the reference, a rejected step only changes the damping: J, Hpp, Hcc, gp, gc are reused.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -149,8 +150,11 @@ struct LMWorkFull : LMWork {
   // facto_type = Float16 (src/lm.jl:165-169): set per solve; J_lin / r_lin / cr0: what the model value of the current step is
   // evaluated on (the Float16-rounded scaled copies in that mode, J and r otherwise), see linear_step
   bool f16 = false;
-  const double *J_lin = nullptr, *r_lin = nullptr;
-  double cr0 = 1.0;
+  // what the model value of a step is evaluated on: the Float16-rounded scaled copies in that branch, J and r otherwise
+  // (looked up at call time: w->r / w->r_trial swap on accepted steps, a recorded graph must not pin them)
+  const double *J_lin() const { return f16 ? Jq : J; }
+  const double *r_lin() const { return f16 ? rq : r; }
+  double cr0() const { return f16 ? 1.0 / (0.1 * 6.55e4) : 1.0; }
   // eltype(x) = Float32 runs (BALNLPModel(file, Float32), src/BALNLPModels.jl:91): x, r and J are produced by the Float32
   // kernels and widened; every iterate is rounded to Float32.  Buffers allocated on first use.
   float *xf = nullptr, *rf = nullptr, *Jf = nullptr;
@@ -239,7 +243,7 @@ static int lm_ensure(ba_problem *p) {
   BA_CHECK(dmalloc(&w->Yobs, 6 * nobs));
   BA_CHECK(dmalloc(&w->Hcc, 45 * ncams));
   BA_CHECK(dmalloc(&w->colscale, 9 * ncams));
-  BA_CHECK(dmalloc(&w->partial, (int64_t)RED_BLOCKS));
+  BA_CHECK(dmalloc(&w->partial, std::max<int64_t>(RED_BLOCKS, (npnts + 255) / 256)));  // k_backsub_st: one partial per 256 points
   BA_CHECK(dmalloc(&w->s.scal_rep, (int64_t)RP_COUNT));
   BA_HIP_CHECK(hipHostMalloc((void **)&w->s.h_sh, SH_COUNT * sizeof(double)));
   BA_HIP_CHECK(hipHostMalloc((void **)&w->s.h_rp, RP_COUNT * sizeof(double)));
@@ -365,9 +369,6 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
     damp = w->damp;
     normalize = 0;  // lm.jl:156,232: no column scaling of J in the Float16 branch
   }
-  w->J_lin = Jl;
-  w->r_lin = rl;
-  w->cr0 = w->f16 ? 1.0 / MU16 : 1.0;
   BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, d_lambda, damp));
   BA_CHECK(launch_schur_blocks(p, &w->tasks, Jl, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
                                p->rank == 0 ? w->npad : w->n, st, d_lambda, damp));
@@ -403,15 +404,19 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   double *dc = w->delta + 3 * p->npnts;
   if (normalize != 0) BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));  // dc = D^-1 dc'
   BA_HIP_CHECK(hipMemcpyAsync(dc, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BA_CHECK(launch_backsub(p, Jl, w->Uinv, w->u, dc, w->delta, st));
+  // the model value of the step rides along with the back-substitution (not in the Float16 branch: its step is rescaled below)
+  BA_CHECK(launch_backsub(p, Jl, w->Uinv, w->u, dc, w->delta, st, w->f16 ? nullptr : rl, w->cr0(), w->partial, w->scal, SH_MODEL,
+                          &w->model_done));
   if (w->f16) BA_CHECK(launch_scale_scalar(p, w->nvar, w->delta, 1.0 / MU16, st));  // the right-hand side was -Jh' r / mu
   return BA_OK;
 }
 
 // cr: the model value is |J delta + cr r|^2 (1 outside the line search)
 static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st, double cr = -1.0) {
-  if (cr < 0) cr = w->cr0;
-  BA_CHECK(launch_model_sq(p, w->J_lin, w->r_lin, w->delta, w->partial, w->scal, SH_MODEL, st, cr));
+  const bool first = cr < 0;  // the step as linear_step left it (the line search calls with a rescaled delta and its own cr)
+  if (first) cr = w->cr0();
+  if (!(first && w->model_done)) BA_CHECK(launch_model_sq(p, w->J_lin(), w->r_lin(), w->delta, w->partial, w->scal, SH_MODEL, st, cr));
+  w->model_done = false;
   BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->delta, w->partial, w->scal, SH_DELTA_P, st));
   BA_CHECK(launch_sumsq(p, w->n, w->delta + 3 * p->npnts, w->partial, w->s.scal_rep, RP_DELTA_C, st));
   return BA_OK;
@@ -707,7 +712,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
       pred = obj - dr2;
       ared = obj - obj_suiv;
       step_accepted = ared >= 1e-4 * pred;  // lm.jl:257-259
-      double c_r = w->cr0;  // delta_r = -(J delta + c_r r)   (1; 1/mu in the Float16 branch)
+      double c_r = w->cr0();  // delta_r = -(J delta + c_r r)   (1; 1/mu in the Float16 branch)
       while (linesearch && !step_accepted && ntimes < 4) {  // lm.jl:264-295
         // delta /= delta_d ; delta_r = (delta_r - r)/delta_d (lm.jl:277): with delta_r = -(J delta + c r) the update is
         // c <- (c + 1)/delta_d, which stays 1 only for the default delta_d = 2 (the reference's comment at lm.jl:275-276

@@ -22,6 +22,7 @@ struct LMWork {
   double *r = nullptr, *r_trial = nullptr, *J = nullptr;
   double *Hpp = nullptr, *gp = nullptr, *Uinv = nullptr, *u = nullptr;
   double *Yobs = nullptr;                // 6/obs: U^-1 A_b' of the current damping
+  bool model_done = false;               // the step's model value was formed by the back-substitution pass
   double *Hcc = nullptr, *gc = nullptr;  // gc: 9*ncams
   double *hdiag = nullptr;               // npad: diag of the camera block of J'J summed over all ranks (column scalings)
   double *rhs = nullptr;                 // npad
@@ -48,7 +49,8 @@ int launch_f16_scale(ba_problem *p, double lambda, double mu, const double *d_jn
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
                      hipStream_t st);
 int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,
-                   double *d_dp, hipStream_t st);
+                   double *d_dp, hipStream_t st, const double *d_r_model = nullptr, double cr = 1.0, double *d_partial = nullptr,
+                   double *d_scal = nullptr, int slot = 0, bool *model_done = nullptr);
 int launch_model_sq(ba_problem *p, const double *d_J, const double *d_r, const double *d_delta, double *d_partial,
                     double *d_scal, int slot, hipStream_t st, double cr = 1.0);
 int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial, double *d_scal, int slot,

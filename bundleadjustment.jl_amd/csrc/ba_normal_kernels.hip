@@ -122,6 +122,118 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_
   }
 }
 
+// ---- coalesced row staging ------------------------------------------------------------------------------------------
+// A lane that reads "its" observation's 24 doubles with scalar loads touches 64 different 192-byte rows per instruction.
+// Here a wave stages the rows of 64 observations into its LDS slot with 16-byte loads in which 12 consecutive lanes read
+// one whole row (12 instructions per 64 rows), and each lane then works on its row from LDS (row stride 25 doubles:
+// conflict-free).  rows == null: observations q0 .. q0+nrows-1 (contiguous); else observation rows[q0 + i].
+// Measured on Venice (bench.py kernel classes, ms per launch, plain -> staged): right-hand side pass (k_cam_blocks<2>)
+// 0.68 -> 0.47; back-substitution + model value in one staged pass 0.48 + 0.37 -> 0.76; but the 54-accumulator Hcc pass
+// 0.32 -> 0.50 and the point-block pass 0.27 -> 0.33 got SLOWER and keep their plain loads: the vector L1 already merges
+// the 24 strided loads of a wave, and the PMC "over-fetch" of those kernels (FETCH_SIZE x 2) overstates 8-byte loads.
+constexpr int JLD = 25;
+constexpr int ST_WAVE_ELEMS = 64 * JLD;
+typedef double d2n __attribute__((ext_vector_type(2)));
+
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ inline void stage_rows(const double *__restrict__ J, const int *__restrict__ rows, int64_t q0, int nrows,
+                                  double *slot) {
+  const int lane = threadIdx.x & 63;
+  d2n v[12];
+#pragma unroll
+  for (int ps = 0; ps < 12; ps++) {  // piece f = 64 ps + lane of the 768 16-byte pieces: row f / 12, piece f % 12
+    const int f = ps * 64 + lane;
+    int r = f / 12;
+    const int pc = f - 12 * r;
+    r = r < nrows ? r : nrows - 1;  // clamped, not predicated: a load under a per-lane condition serialises
+    const int64_t o = rows ? (int64_t)rows[q0 + r] : q0 + r;
+    v[ps] = *reinterpret_cast<const d2n *>(J + 24 * o + 2 * pc);
+  }
+#pragma unroll
+  for (int ps = 0; ps < 12; ps++) {
+    const int f = ps * 64 + lane;
+    const int r = f / 12, pc = f - 12 * r;
+    slot[r * JLD + 2 * pc] = v[ps].x;
+    slot[r * JLD + 2 * pc + 1] = v[ps].y;
+  }
+  wave_lds_sync();
+}
+
+// camera side with staged rows: same work item, same summation order as k_cam_blocks (thread t of camera c takes list
+// positions t, t + 256, ...), hence the same bits
+template <int MODE>
+__global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ cam_ptr, const int *__restrict__ cam_obs,
+                                                        const int *__restrict__ pnt0, const double *__restrict__ J,
+                                                        const double *__restrict__ r, const double *__restrict__ u,
+                                                        double *__restrict__ Hcc, double *__restrict__ out9) {
+  constexpr int NACC = (MODE == 0) ? 54 : 9;
+  __shared__ double slots[(BLK / 64) * ST_WAVE_ELEMS];
+  __shared__ double red[BLK / 64][NACC];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double *slot = slots + wv * ST_WAVE_ELEMS;
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; i++) acc[i] = 0;
+  const int qend = cam_ptr[c + 1];
+  for (int q0 = cam_ptr[c] + wv * 64; q0 < qend; q0 += BLK) {  // wave-uniform
+    const int nrows = qend - q0 < 64 ? qend - q0 : 64;
+    stage_rows(J, cam_obs, q0, nrows, slot);
+    if (lane < nrows) {
+      const int64_t o = cam_obs[q0 + lane];
+      const double *Jo = slot + lane * JLD;
+      double b0[9], b1[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        b0[i] = Jo[3 + i];
+        b1[i] = Jo[15 + i];
+      }
+      double w0, w1;
+      if (MODE == 2) {
+        const double *up = u + 3 * (int64_t)pnt0[o];
+        w0 = (Jo[0] * up[0] + Jo[1] * up[1] + Jo[2] * up[2]) - r[2 * o];
+        w1 = (Jo[12] * up[0] + Jo[13] * up[1] + Jo[14] * up[2]) - r[2 * o + 1];
+      } else {
+        w0 = r[2 * o];
+        w1 = r[2 * o + 1];
+      }
+      if (MODE == 0) {
+        int idx = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+          for (int j = 0; j <= i; j++) acc[idx++] += b0[i] * b0[j] + b1[i] * b1[j];
+#pragma unroll
+        for (int i = 0; i < 9; i++) acc[45 + i] += b0[i] * w0 + b1[i] * w1;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) acc[i] += b0[i] * w0 + b1[i] * w1;
+      }
+    }
+    wave_lds_sync();  // the slot is rewritten by the next batch
+  }
+#pragma unroll
+  for (int i = 0; i < NACC; i++) {
+    double v = wave_sum(acc[i]);
+    if (lane == 0) red[wv][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (MODE == 0) {
+      if (threadIdx.x < 45) Hcc[45 * (int64_t)c + threadIdx.x] = v;
+      else out9[9 * (int64_t)c + threadIdx.x - 45] = v;
+    } else {
+      out9[9 * (int64_t)c + threadIdx.x] = v;
+    }
+  }
+}
+
 // ---- per point: U^-1 = (Hpp + lambda I)^-1 (6, symmetric) and u = U^-1 gp -------------------------------------
 // lam_dev (here and below): when non-null the damping is lambda * lam_dev[0] -- a launch recorded in a hipGraph keeps
 // its arguments, so the replayed LM iteration reads the current damping from device memory.
@@ -425,6 +537,87 @@ __global__ __launch_bounds__(BLK) void k_model_sq(int64_t nobs, int64_t npnts, c
   if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// Back-substitution with staged rows (point-sorted observations), one lane per point as k_backsub, and -- because the rows
+// and dc are at hand -- the model value 1/2 |J delta + cr r|^2 of the step in the same pass over J (a second sweep over the
+// wave's row range, L2-warm): partial[blockIdx.x] = this block's part of sum |J delta + cr r|^2 (r == null: not wanted).
+__global__ __launch_bounds__(BLK) void k_backsub_st(int64_t npnts, const int *__restrict__ pt_ptr, const int *__restrict__ cam0,
+                                                     const double *__restrict__ J, const double *__restrict__ Uinv,
+                                                     const double *__restrict__ u, const double *__restrict__ dc,
+                                                     double *__restrict__ dp, const double *__restrict__ r, double cr,
+                                                     double *__restrict__ partial) {
+  __shared__ double slots[(BLK / 64) * ST_WAVE_ELEMS];
+  __shared__ double red[BLK / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t p0 = (int64_t)blockIdx.x * BLK + wv * 64;
+  double acc = 0;
+  if (p0 < npnts) {  // wave-uniform
+    double *slot = slots + wv * ST_WAVE_ELEMS;
+    const int64_t p = p0 + lane, plast = p0 + 64 < npnts ? p0 + 64 : npnts;
+    const int qb = pt_ptr[p0], qe = pt_ptr[plast];
+    const int mb = p < npnts ? pt_ptr[p] : qe, me = p < npnts ? pt_ptr[p + 1] : qe;
+    double w[3] = {0, 0, 0};
+    for (int q0 = qb; q0 < qe; q0 += 64) {
+      const int nrows = qe - q0 < 64 ? qe - q0 : 64;
+      stage_rows(J, nullptr, q0, nrows, slot);
+      const int lo = mb > q0 ? mb : q0, hi = me < q0 + 64 ? me : q0 + 64;
+      for (int q = lo; q < hi; q++) {
+        const double *Jo = slot + (q - q0) * JLD;
+        const double *d = dc + 9 * (int64_t)cam0[q];
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+          s0 += Jo[3 + i] * d[i];
+          s1 += Jo[15 + i] * d[i];
+        }
+        w[0] += Jo[0] * s0 + Jo[12] * s1;
+        w[1] += Jo[1] * s0 + Jo[13] * s1;
+        w[2] += Jo[2] * s0 + Jo[14] * s1;
+      }
+      wave_lds_sync();
+    }
+    double d3[3] = {0, 0, 0};
+    if (p < npnts) {
+      const double *U = Uinv + 6 * p;
+      d3[0] = -(u[3 * p + 0] + (U[0] * w[0] + U[1] * w[1] + U[2] * w[2]));
+      d3[1] = -(u[3 * p + 1] + (U[1] * w[0] + U[3] * w[1] + U[4] * w[2]));
+      d3[2] = -(u[3 * p + 2] + (U[2] * w[0] + U[4] * w[1] + U[5] * w[2]));
+      dp[3 * p + 0] = d3[0];
+      dp[3 * p + 1] = d3[1];
+      dp[3 * p + 2] = d3[2];
+    }
+    if (r) {
+      for (int q0 = qb; q0 < qe; q0 += 64) {
+        const int nrows = qe - q0 < 64 ? qe - q0 : 64;
+        stage_rows(J, nullptr, q0, nrows, slot);
+        const int lo = mb > q0 ? mb : q0, hi = me < q0 + 64 ? me : q0 + 64;
+        for (int q = lo; q < hi; q++) {
+          const double *Jo = slot + (q - q0) * JLD;
+          const double *d = dc + 9 * (int64_t)cam0[q];
+          double s0 = cr * r[2 * (int64_t)q], s1 = cr * r[2 * (int64_t)q + 1];
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            s0 += Jo[i] * d3[i];
+            s1 += Jo[12 + i] * d3[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 9; i++) {
+            s0 += Jo[3 + i] * d[i];
+            s1 += Jo[15 + i] * d[i];
+          }
+          acc += s0 * s0 + s1 * s1;
+        }
+        wave_lds_sync();
+      }
+    }
+  }
+  if (r) {
+    acc = wave_sum(acc);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+  }
+}
+
 // sum of squares of a vector -> per-block partials (fixed grid => fixed summation tree)
 __global__ __launch_bounds__(BLK) void k_sumsq(int64_t n, const double *__restrict__ v, double *__restrict__ partial) {
   __shared__ double red[BLK / 64];
@@ -470,6 +663,12 @@ __global__ __launch_bounds__(BLK) void k_scale_vec(int64_t n, const double *__re
 
 static inline unsigned grid_for(int64_t n, int blk) { return (unsigned)((n + blk - 1) / blk); }
 
+// BA_STAGED=0: the scalar-load kernels of round 1 everywhere (A/B measurements)
+static bool staged_on() {
+  static const bool off = [] { const char *e = getenv("BA_STAGED"); return e && e[0] == '0'; }();
+  return !off;
+}
+
 int launch_point_blocks(ba_problem *p, const double *d_J, const double *d_r, double *d_Hpp, double *d_gp,
                         hipStream_t st) {
   if (p->npnts == 0) return BA_OK;
@@ -484,9 +683,14 @@ int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, doubl
                       hipStream_t st) {
   if (p->ncams == 0) return BA_OK;
   ProfScope ps(p, PC_CAM_BLOCKS, st);
+  // the 54-accumulator Hcc pass is faster with plain per-lane loads (0.32 against 0.50 ms on Venice); the light passes
+  // (J'r here, the right-hand side in launch_schur_rhs) are latency-bound and gain from the staged rows (0.68 -> 0.47 ms)
   if (d_Hcc)
     hipLaunchKernelGGL(k_cam_blocks<0>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
                        d_r, (const double *)nullptr, d_Hcc, d_gc);
+  else if (staged_on())
+    hipLaunchKernelGGL(k_cam_blocks_st<1>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
+                       d_r, (const double *)nullptr, (double *)nullptr, d_gc);
   else
     hipLaunchKernelGGL(k_cam_blocks<1>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
                        d_r, (const double *)nullptr, (double *)nullptr, d_gc);
@@ -550,18 +754,37 @@ int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const 
                      hipStream_t st) {
   if (p->ncams == 0) return BA_OK;
   ProfScope ps(p, PC_SCHUR_RHS, st);
-  hipLaunchKernelGGL(k_cam_blocks<2>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
-                     d_r, d_u, (double *)nullptr, d_rhs);
+  if (staged_on())
+    hipLaunchKernelGGL(k_cam_blocks_st<2>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
+                       d_r, d_u, (double *)nullptr, d_rhs);
+  else
+    hipLaunchKernelGGL(k_cam_blocks<2>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
+                       d_r, d_u, (double *)nullptr, d_rhs);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
 
+// d_r_model != null (and the staged kernel applies): |J delta + cr r|^2 of the step is formed in the same pass ->
+// d_scal[slot], *model_done = true.  d_partial then needs one entry per block of 256 points.
 int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,
-                   double *d_dp, hipStream_t st) {
+                   double *d_dp, hipStream_t st, const double *d_r_model, double cr, double *d_partial, double *d_scal,
+                   int slot, bool *model_done) {
+  if (model_done) *model_done = false;
   if (p->npnts == 0) return BA_OK;
   ProfScope ps(p, PC_BACKSUB, st);
-  hipLaunchKernelGGL(k_backsub, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->pt_obs, p->cam0,
-                     d_J, d_Uinv, d_u, d_dc, d_dp);
+  const unsigned nb = grid_for(p->npnts, BLK);
+  if (p->point_sorted && staged_on()) {
+    const bool with_model = d_r_model && d_partial && d_scal;
+    hipLaunchKernelGGL(k_backsub_st, dim3(nb), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->cam0, d_J, d_Uinv, d_u, d_dc, d_dp,
+                       with_model ? d_r_model : (const double *)nullptr, cr, d_partial);
+    if (with_model) {
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLK), 0, st, (int)nb, d_partial, d_scal, slot);
+      if (model_done) *model_done = true;
+    }
+  } else {
+    hipLaunchKernelGGL(k_backsub, dim3(nb), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->pt_obs, p->cam0, d_J, d_Uinv, d_u, d_dc,
+                       d_dp);
+  }
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }

@@ -3,6 +3,13 @@
 // time the very kernels that ship.
 #include "../ba_dense_ldl.hip"
 
+namespace {
+__global__ void k_probe_fill(double *a, size_t n, double scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = scale * (double)((i * 2654435761u) % 1021) / 1021.0 - 0.3;
+}
+}  // namespace
+
 static int set_bench_kernel_attrs() {
   typedef double T;
   BA_CHECK(set_kernel_attrs<T>());
@@ -12,6 +19,10 @@ static int set_bench_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 8>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 16>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 17>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 9>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
   return BA_OK;
@@ -26,6 +37,10 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   BA_HIP_CHECK(hipMalloc((void **)&V, (size_t)2 * nt * NB * NB * sizeof(double)));
   BA_HIP_CHECK(hipMemset(S, 0, tiles * sizeof(double)));
   BA_HIP_CHECK(hipMemset(V, 0, (size_t)2 * nt * NB * NB * sizeof(double)));
+  if (getenv("BA_BENCH_NONZERO")) {  // operands with real bit patterns (power / clocks differ from all-zero data)
+    hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, 0, S, tiles, 1e-3);
+    hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)(((size_t)2 * nt * NB * NB + 255) / 256)), dim3(256), 0, 0, V, (size_t)2 * nt * NB * NB, 1e-3);
+  }
   const int m = nt - 2, nblk = m * (m + 1) / 2, grid = ((nblk + 7) / 8) * 8;
   std::vector<int64_t> h_co;
   dense_ldl_layout(nt, 1, &h_co, nullptr);
@@ -41,6 +56,8 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
       case 1: hipLaunchKernelGGL((k_ldl_update<double, 1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       case 2: hipLaunchKernelGGL((k_ldl_update<double, 1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       case 8: hipLaunchKernelGGL((k_ldl_update<double, 1, 8>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 16: hipLaunchKernelGGL((k_ldl_update<double, 1, 16>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 17: hipLaunchKernelGGL((k_ldl_update<double, 1, 17>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       case 9: hipLaunchKernelGGL((k_ldl_update<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       default: hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr);
     }
@@ -227,6 +244,84 @@ __global__ __launch_bounds__(256, (NCB == 8 ? 1 : 2)) void k_stage_probe(const d
   }
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
+// Mode 5: the same wave-private loop with LDS-DMA staging (global_load_lds_dwordx4: no staging VGPRs, no ds_write): chunks of 8,
+// two LDS buffers per wave (16 KB per wave, 64 KB per workgroup), the next chunk's 8 DMA pieces in flight during the MFMAs, the
+// wave waits with vmcnt only -- no barrier.  A DMA piece lands at base + lane * 16: rows are unpadded (64 B), so the 16-byte
+// columns are XOR-swizzled with the row ((row >> 2) & 3) to keep the MFMA operand reads at two dwords per bank.
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void k_dma_probe(const double *__restrict__ Aop, const double *__restrict__ Bop, double *out,
+                                                      int tiles_per_wg, int ntile_rows) {
+  typedef double d4p __attribute__((ext_vector_type(4)));
+  constexpr int DKC = 8, NCHK = 256 / DKC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  double *lds = reinterpret_cast<double *>(smraw);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fk = lane >> 4;
+  double *wbase = lds + wv * (2 * 2 * 64 * DKC);  // [buffer][A | B][64 rows][8]
+  const int prow = lane >> 2, pc2 = lane & 3;     // a piece: 16 rows x 64 B; this lane's row and 16-byte slot inside it
+  d4p acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < 4; n++) acc[m][n] = (d4p){0, 0, 0, 0};
+  // operand read offsets (doubles) inside a 64 x 8 slice: row r, element k -> r * 8 + (((k >> 1) ^ ((r >> 2) & 3)) << 1) + (k & 1)
+  int offA[2][4], offB[2][4];
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int r = 16 * m + fr, k = 4 * kk + fk;
+      offA[kk][m] = r * DKC + ((((k >> 1) ^ ((r >> 2) & 3))) << 1) + (k & 1);
+      offB[kk][m] = offA[kk][m];
+    }
+  for (int t = 0; t < tiles_per_wg; t++) {
+    const int ti = (blockIdx.x * 7 + t * 3) % ntile_rows, tj = (blockIdx.x * 5 + t) % ntile_rows;
+    const double *Ab = Aop + (size_t)ti * NB * NB + (size_t)((wv >> 1) * 64) * NB;
+    const double *Bb = Bop + (size_t)tj * NB * NB + (size_t)((wv & 1) * 64) * NB;
+    auto issue = [&](int ch) {  // 8 DMA pieces: chunk ch of A and B into buffer ch & 1
+      double *dst = wbase + (ch & 1) * (2 * 64 * DKC);
+      const int k0 = (ch & (128 / DKC - 1)) * DKC;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = 16 * q + prow;
+        const int c2 = pc2 ^ ((r >> 2) & 3);
+        __builtin_amdgcn_global_load_lds(Ab + (size_t)r * NB + k0 + 2 * c2, dst + q * 16 * DKC, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(Bb + (size_t)r * NB + k0 + 2 * c2, dst + 64 * DKC + q * 16 * DKC, 16, 0, 0);
+      }
+    };
+    issue(0);
+    for (int ch = 0; ch < NCHK; ch++) {
+      if (ch + 1 < NCHK) {
+        issue(ch + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk ch has landed, chunk ch + 1 (8 pieces) may still be in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const double *cA = wbase + (ch & 1) * (2 * 64 * DKC), *cB = cA + 64 * DKC;
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) af[m] = cA[offA[kk][m]];
+#pragma unroll
+        for (int n = 0; n < 4; n++) bf[n] = cB[offB[kk][n]];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  double s = 0;
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    double sn = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) sn += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    s += sn;
+  }
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace
 
 extern "C" int ba_debug_mfma_probe(int mode, int iters, double *tflops_out) {
@@ -259,20 +354,26 @@ extern "C" int ba_debug_mfma_probe(int mode, int iters, double *tflops_out) {
     const double nc = mode == 2 ? 8 : 4;
     flops = (double)grid * 4 /*waves*/ * iters * 4 /*kk*/ * 4 * nc * 2048.0;
   } else {
-    const int ncb = mode == 3 ? 4 : 8, per_cu = mode == 3 ? 2 : 1, grid = ncu * per_cu, tiles = iters > 0 ? iters : 16;
+    const int ncb = mode == 4 ? 8 : 4, per_cu = mode == 4 ? 1 : 2, grid = ncu * per_cu, tiles = iters > 0 ? iters : 16;
     const int ntile_rows = 120;  // 2 x 15.7 MB of operands: cache-resident like the panels of a pair update
-    const size_t lds_bytes = (size_t)4 * (64 + 16 * ncb) * 18 * sizeof(double);
+    const size_t lds_bytes = mode == 5 ? (size_t)4 * 2 * 2 * 64 * 8 * sizeof(double) : (size_t)4 * (64 + 16 * ncb) * 18 * sizeof(double);
     BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)grid * 256 * sizeof(double)));
     BA_HIP_CHECK(hipMalloc((void **)&Aop, (size_t)ntile_rows * NB * NB * sizeof(double)));
     BA_HIP_CHECK(hipMalloc((void **)&Bop, (size_t)ntile_rows * NB * NB * sizeof(double)));
-    BA_HIP_CHECK(hipMemset(Aop, 0, (size_t)ntile_rows * NB * NB * sizeof(double)));
-    BA_HIP_CHECK(hipMemset(Bop, 0, (size_t)ntile_rows * NB * NB * sizeof(double)));
-    if (mode == 3)
+    {  // non-trivial operands: the checksum of out[] must be the same for every staging variant (same products, same order)
+      const size_t ne = (size_t)ntile_rows * NB * NB;
+      hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, 0, Aop, ne, 1.0);
+      hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, 0, Bop, ne, 0.7);
+    }
+    if (mode == 5)
+      BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dma_probe<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    else if (mode == 3)
       BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_probe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     else
       BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_stage_probe<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     auto launch = [&]() {
-      if (mode == 3) hipLaunchKernelGGL(k_stage_probe<4>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
+      if (mode == 5) hipLaunchKernelGGL(k_dma_probe<0>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
+      else if (mode == 3) hipLaunchKernelGGL(k_stage_probe<4>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
       else hipLaunchKernelGGL(k_stage_probe<8>, dim3(grid), dim3(256), lds_bytes, 0, Aop, Bop, out, tiles, ntile_rows);
     };
     launch();
@@ -283,6 +384,13 @@ extern "C" int ba_debug_mfma_probe(int mode, int iters, double *tflops_out) {
     BA_HIP_CHECK(hipEventSynchronize(e1));
     BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     flops = (double)grid * 4 * tiles * 16 /*chunks*/ * 4 /*kk*/ * 4 * ncb * 2048.0;
+    {
+      std::vector<double> h((size_t)grid * 256);
+      BA_HIP_CHECK(hipMemcpy(h.data(), out, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+      double cs = 0, ca = 0;
+      for (double v : h) { cs += v; ca += std::fabs(v); }
+      fprintf(stderr, "[probe] mode %d: checksum %.17g (abs %.17g) over %zu values\n", mode, cs, ca, h.size());
+    }
   }
   *tflops_out = flops / (ms * 1e-3) / 1e12;
   if (out) (void)hipFree(out);

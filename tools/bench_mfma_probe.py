@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _benchlib
 ba, L = _benchlib.load()
 L.ba_debug_mfma_probe.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
-for mode in (0, 1, 2, 3, 4, 3, 4):
+for mode in ([int(m) for m in sys.argv[1].split(',')] if len(sys.argv) > 1 else (0, 1, 2, 3, 4, 5, 3, 5)):
     tf = C.c_double(0)
-    rc = L.ba_debug_mfma_probe(mode, 2000 if mode <= 2 else 16, C.byref(tf))
+    rc = L.ba_debug_mfma_probe(mode, 2000 if mode <= 2 else int(sys.argv[2]) if len(sys.argv) > 2 else 16, C.byref(tf))
     print(f"mode {mode}: {tf.value:.1f} TFLOP/s (rc {rc})", flush=True)
