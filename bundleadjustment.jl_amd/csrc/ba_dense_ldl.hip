@@ -1135,6 +1135,53 @@ __global__ __launch_bounds__(256) void k_bwd_step(const T *__restrict__ S, const
   if (tid < NB) y[(int64_t)j * NB + tid] -= D[(int64_t)j * NB + tid] * (part[0][tid] + part[1][tid]);
 }
 
+// backward steps k and k-1 in one launch (the sweep is a chain of nt dependent launches of ~13 us each: two panels per
+// launch halve it).  Every workgroup recomputes x_k, the correction of y_{k-1} and x_{k-1} (three 128 x 128 products on
+// L2-resident tiles); block 0 stores them, block j+1 applies both panels to y_j, j < k-1.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
+                                                   const T *__restrict__ D, T *__restrict__ y, T *__restrict__ x, int k) {
+  __shared__ T zk[NB], xk[NB], xk1[NB], part[2][NB];
+  const int tid = threadIdx.x;
+  const int c = tid & (NB - 1), half = tid >> 7;
+  auto matvec_t = [&](const T *M, const T *v) {  // part[half][c] = sum over this half's 64 rows of M[r][c] v[r]
+    T s = 0;
+    for (int r = half * 64; r < half * 64 + 64; r++) s += M[r * NB + c] * v[r];
+    part[half][c] = s;
+  };
+  if (tid < NB) zk[tid] = y[(int64_t)k * NB + tid] / D[(int64_t)k * NB + tid];
+  __syncthreads();
+  matvec_t(Linv + (int64_t)k * NB * NB, zk);
+  __syncthreads();
+  if (tid < NB) xk[tid] = part[0][tid] + part[1][tid];
+  __syncthreads();
+  matvec_t(S + tix(co, k, k - 1) * NB * NB, xk);  // L_{k,k-1}' x_k
+  __syncthreads();
+  if (tid < NB) {
+    const T d = D[(int64_t)(k - 1) * NB + tid];
+    zk[tid] = (y[(int64_t)(k - 1) * NB + tid] - d * (part[0][tid] + part[1][tid])) / d;
+  }
+  __syncthreads();
+  matvec_t(Linv + (int64_t)(k - 1) * NB * NB, zk);
+  __syncthreads();
+  if (tid < NB) xk1[tid] = part[0][tid] + part[1][tid];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (tid < NB) {
+      x[(int64_t)k * NB + tid] = xk[tid];
+      x[(int64_t)(k - 1) * NB + tid] = xk1[tid];
+    }
+    return;
+  }
+  const int j = blockIdx.x - 1;  // 0 .. k-2
+  const T *Lkj = S + tix(co, k, j) * NB * NB, *Lk1j = S + tix(co, k - 1, j) * NB * NB;
+  T s = 0;
+  for (int r = half * 64; r < half * 64 + 64; r++) s += Lkj[r * NB + c] * xk[r] + Lk1j[r * NB + c] * xk1[r];
+  part[half][c] = s;
+  __syncthreads();
+  if (tid < NB) y[(int64_t)j * NB + tid] -= D[(int64_t)j * NB + tid] * (part[0][tid] + part[1][tid]);
+}
+
 }  // namespace
 
 int64_t dense_ldl_tiles_doubles(int64_t n_unpadded) {
@@ -1489,7 +1536,12 @@ int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool
   if (!forward_done)
     for (int k = 0; k < nt; k++)
       hipLaunchKernelGGL(k_fwd_step<T>, dim3(nt - k), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k);
-  for (int k = nt - 1; k >= 0; k--)
+  static const bool pair_off = [] { const char *e = getenv("BA_BWD_PAIR"); return e && e[0] == '0'; }();
+  int k = nt - 1;
+  if (!pair_off)
+    for (; k >= 1; k -= 2)  // panels k, k-1 per launch; blocks: 1 + (k-1) tile rows below the pair
+      hipLaunchKernelGGL(k_bwd_pair<T>, dim3(k), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, k);
+  for (; k >= 0; k--)
     hipLaunchKernelGGL(k_bwd_step<T>, dim3(k + 1), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, k);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;

@@ -311,6 +311,8 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
   const int fr = lane & 15, fk = lane >> 4, tl = fk >> 1, al = fk & 1;
   // grid-stride over the keys: the AQL grid size is a 32-bit count of work-items, and Final-13682 has 93.6 M keys
   // (x 64 lanes > 2^32): a one-wave-per-key launch silently dropped the tail (zero pivots at the first lost diagonal).
+  // (Tried: giving each XCD a contiguous eighth of the (camera_a, camera_b)-sorted keys so that a camera's own rows are
+  // re-read from that XCD's L2 -- 4.3 -> 5.1 ms on Venice, slower: the interleaved order stays.)
   for (int64_t key = (int64_t)blockIdx.x * (BLK / 64) + wv; key < nkeys; key += (int64_t)gridDim.x * (BLK / 64)) {
   const int ca = key_ca[key], cb = key_cb[key];
   const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
