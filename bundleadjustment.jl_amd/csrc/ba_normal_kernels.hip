@@ -298,6 +298,10 @@ __global__ __launch_bounds__(BLK) void k_obs_y(int64_t nobs, const int *__restri
 // B operand G[alpha][j] = Q_ab[alpha][:] B_b[:][j] with Q_ab = A_a Y_b.  Per task one coalesced load of
 // J_a (24), the camera rows of J_b (18) and Y_b (6) is staged in the wave's LDS slot.
 typedef double d4s __attribute__((ext_vector_type(4)));
+#ifndef BA_SCHUR_PF
+#define BA_SCHUR_PF 2  // task pairs in flight per wave: 2, 3, 4 measure the same (6.29-6.42 ms on the sweep box), 6 and 8 slower (7.7)
+#endif
+constexpr int SCHUR_PF = BA_SCHUR_PF;
 __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *__restrict__ key_ptr,
                                                        const int *__restrict__ key_ca, const int *__restrict__ key_cb,
                                                        const int *__restrict__ task_a, const int *__restrict__ task_b,
@@ -337,13 +341,22 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
       if (e < 48) return Y[6 * (int64_t)ob + eoff];
       return 0.0;
     };
-    double p0a = fetch(0), p0b = fetch(1), p1a = fetch(2), p1b = fetch(3);
+    // SCHUR_PF task pairs in flight per wave (an average key has ~11 tasks: most of a key's records are requested at once)
+    double pf[SCHUR_PF][2];
+#pragma unroll
+    for (int q = 0; q < SCHUR_PF; q++) {
+      pf[q][0] = fetch(2 * q);
+      pf[q][1] = fetch(2 * q + 1);
+    }
     for (int tp = 0; tp < nin; tp += 2) {
-      const double ca_v = p0a, cb_v = p0b;
-      p0a = p1a;
-      p0b = p1b;
-      p1a = fetch(tp + 4);
-      p1b = fetch(tp + 5);
+      const double ca_v = pf[0][0], cb_v = pf[0][1];
+#pragma unroll
+      for (int q = 0; q + 1 < SCHUR_PF; q++) {
+        pf[q][0] = pf[q + 1][0];
+        pf[q][1] = pf[q + 1][1];
+      }
+      pf[SCHUR_PF - 1][0] = fetch(tp + 2 * SCHUR_PF);
+      pf[SCHUR_PF - 1][1] = fetch(tp + 2 * SCHUR_PF + 1);
       if (e < 48) {
         stage[wv][0][e] = ca_v;
         stage[wv][1][e] = cb_v;
