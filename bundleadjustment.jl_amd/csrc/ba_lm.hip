@@ -673,6 +673,12 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   double norm_Jtr = std::sqrt(h_sh[SH_GP] + h_rp[RP_GC]);
   double norm_x = std::sqrt(h_sh[SH_X_P] + h_rp[RP_X_C]);
   if (V) lambda = std::fmax(lambda, 1e10 / norm_Jtr);  // lm.jl:59
+  // eltype(x) = Float32: lambda = T(max(...)) is a Float32 there, and so are nu_d, nu_m (lm.jl:25) -- until the first
+  // accepted step, whose `max(1.0e-8, lambda)` (lm.jl:337, a Float64 literal) promotes it to Float64 for the rest of the
+  // run.  (In LevenbergMarquardt.jl lambda = eltype(x)(0.1) stays Float32 throughout: only Float32 operations touch it.)
+  bool lam_f32 = xf32;
+  auto rl32 = [&](double v) { return lam_f32 ? (double)(float)v : v; };
+  lambda = rl32(lambda);
 
   double norm_delta = 0, dr2 = 0, ared = 0, pred = 0;
   const double eps_first = atol + rtol * norm_Jtr;  // lm.jl:107
@@ -755,17 +761,18 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
 
     if (!step_accepted) {
       stats->n_rejected++;
-      if (V) lambda = std::fmax(lambda, 1 / norm_delta) * std::pow(nu_m, (double)(ntimes + 1));  // lm.jl:308
-      else lambda *= nu_m;                                                                          // LevenbergMarquardt.jl:269
+      if (V) lambda = rl32(rl32(std::fmax(lambda, rl32(1 / norm_delta))) * rl32(std::pow(nu_m, (double)(ntimes + 1))));  // lm.jl:308
+      else lambda = rl32(lambda * nu_m);                                                            // LevenbergMarquardt.jl:269
     } else {
       stats->n_accepted++;
       if (V) {  // lm.jl:329-337
-        if (ntimes > 0) lambda /= std::pow(nu_d, (double)(ntimes - 1));
-        else lambda /= nu_d;
-        if (ared >= 0.9 * pred) lambda /= nu_d;
+        if (ntimes > 0) lambda = rl32(lambda / rl32(std::pow(nu_d, (double)(ntimes - 1))));
+        else lambda = rl32(lambda / nu_d);
+        if (ared >= 0.9 * pred) lambda = rl32(lambda / nu_d);
         lambda = std::fmax(1.0e-8, lambda);
+        lam_f32 = false;  // promoted by the Float64 literal
       } else {
-        lambda /= nu_d;  // LevenbergMarquardt.jl:292
+        lambda = rl32(lambda / nu_d);  // LevenbergMarquardt.jl:292
       }
       std::swap(w->x, w->x_trial);  // x .= x_suiv
       std::swap(w->r, w->r_trial);  // r .= r_suiv
