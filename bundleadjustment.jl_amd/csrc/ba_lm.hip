@@ -111,6 +111,34 @@ int build_tasks(ba_problem *p, SchurTasks *T) {
   }
   T->nkeys = (int64_t)key_ca.size();
   T->ntasks = ntasks;
+  {  // chunking of the long keys (see SchurTasks)
+    int ch = 8;
+    while (ch < 32 && ntasks / ch > 8192 * 4) ch *= 2;
+    if (const char *e = getenv("BA_SCHUR_CHUNK")) ch = atoi(e);  // 0 disables the split
+    T->chunk = ch;
+    std::vector<int> skey, skey_c0, ct0, ct1;
+    if (ch > 0)
+      for (int64_t k = 0; k < T->nkeys; k++) {
+        const int t0 = key_ptr[(size_t)k], t1 = key_ptr[(size_t)k + 1];
+        if (t1 - t0 <= 2 * ch) continue;
+        skey.push_back((int)k);
+        skey_c0.push_back((int)ct0.size());
+        for (int t = t0; t < t1; t += ch) {
+          ct0.push_back(t);
+          ct1.push_back(t + ch < t1 ? t + ch : t1);
+        }
+      }
+    skey_c0.push_back((int)ct0.size());
+    T->nsplit = (int64_t)skey.size();
+    T->nchunks = (int64_t)ct0.size();
+    if (T->nsplit > 0) {
+      BA_CHECK(upload_vec(&T->skey, skey));
+      BA_CHECK(upload_vec(&T->skey_c0, skey_c0));
+      BA_CHECK(upload_vec(&T->chunk_t0, ct0));
+      BA_CHECK(upload_vec(&T->chunk_t1, ct1));
+      BA_CHECK(dmalloc(&T->partial, 81 * T->nchunks));
+    }
+  }
   BA_CHECK(upload_vec(&T->key_ptr, key_ptr));
   BA_CHECK(upload_vec(&T->key_ca, key_ca));
   BA_CHECK(upload_vec(&T->key_cb, key_cb));
@@ -267,7 +295,8 @@ void lm_free(ba_problem *p) {
   if (w->Jf) (void)hipFree(w->Jf);
   void *ptrs[] = {w->jn2, w->dcol, w->damp, w->Jq, w->rq, w->x, w->x_trial, w->delta, w->r, w->r_trial, w->J, w->Hpp, w->gp, w->Uinv, w->u, w->Hcc,
                   w->partial, w->colscale, w->Yobs, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
-                  w->tasks.task_a, w->tasks.task_b, w->s.own_red ? w->s.red : nullptr};
+                  w->tasks.task_a, w->tasks.task_b, w->tasks.skey, w->tasks.skey_c0, w->tasks.chunk_t0,
+                  w->tasks.chunk_t1, w->tasks.partial, w->s.own_red ? w->s.red : nullptr};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   for (int q = 0; q < 2; q++) {

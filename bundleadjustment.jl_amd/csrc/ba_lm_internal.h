@@ -7,10 +7,19 @@ constexpr int RED_BLOCKS = 1024;  // fixed number of partial sums => fixed summa
 // Schur task list (built once per problem on the host): all ordered observation pairs (a, b) of one point with
 // camera(a) >= camera(b), sorted by (camera(a), camera(b)); key k owns tasks [key_ptr[k], key_ptr[k+1]).
 // Every camera has its diagonal key even when it has no observation.
+// Long keys (few cameras, many shared points: Dubrovnik-356 has ~80 tasks per key, LadyBug-49 ~70) are split into chunks of
+// `chunk` tasks, one wave per chunk, whose partial 9x9 sums are added up in chunk order by a second kernel: one wave per
+// key would leave most of the chip idle there (63 k waves of 40 dependent iterations each).  Keys of at most 2 chunks' worth
+// of tasks are summed by one wave as before.
 struct SchurTasks {
   int64_t nkeys = 0, ntasks = 0;
   int *key_ptr = nullptr, *key_ca = nullptr, *key_cb = nullptr;  // device
   int *task_a = nullptr, *task_b = nullptr;                       // device
+  int chunk = 0;                                                  // tasks per chunk; keys with more than 2 * chunk tasks are split
+  int64_t nsplit = 0, nchunks = 0;
+  int *skey = nullptr, *skey_c0 = nullptr;                        // split keys: key id, first chunk (nsplit + 1 entries)
+  int *chunk_t0 = nullptr, *chunk_t1 = nullptr;                   // chunks: task range
+  double *partial = nullptr;                                      // nchunks x 81
 };
 
 // scalar slots of LMWork::scal (device) / h_scal (pinned host)

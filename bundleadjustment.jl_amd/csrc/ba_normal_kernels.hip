@@ -302,30 +302,17 @@ typedef double d4s __attribute__((ext_vector_type(4)));
 #define BA_SCHUR_PF 2  // task pairs in flight per wave: 2, 3, 4 measure the same (6.29-6.42 ms on the sweep box), 6 and 8 slower (7.7)
 #endif
 constexpr int SCHUR_PF = BA_SCHUR_PF;
-__global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *__restrict__ key_ptr,
-                                                       const int *__restrict__ key_ca, const int *__restrict__ key_cb,
-                                                       const int *__restrict__ task_a, const int *__restrict__ task_b,
-                                                       const double *__restrict__ J, const double *__restrict__ Y,
-                                                       const double *__restrict__ Hcc, double lambda,
-                                                       const double *__restrict__ lam_dev, double *__restrict__ S,
-                                                       const int64_t *__restrict__ co, const double *__restrict__ damp_c) {
-  __shared__ double stage[BLK / 64][2][48];
-  if (lam_dev) lambda *= lam_dev[0];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// sum over the tasks [t_begin, t_end) of B_a' (Q_ab B_b): lane (fr < 9, i = fk + 4 g < 9) gets element (i, j = fr) in acc[g]
+__device__ inline d4s schur_accumulate(int t_begin, int t_end, const int *__restrict__ task_a, const int *__restrict__ task_b,
+                                       const double *__restrict__ J, const double *__restrict__ Y, double (*stage)[48]) {
+  const int lane = threadIdx.x & 63;
   const int fr = lane & 15, fk = lane >> 4, tl = fk >> 1, al = fk & 1;
-  // grid-stride over the keys: the AQL grid size is a 32-bit count of work-items, and Final-13682 has 93.6 M keys
-  // (x 64 lanes > 2^32): a one-wave-per-key launch silently dropped the tail (zero pivots at the first lost diagonal).
-  // (Tried: giving each XCD a contiguous eighth of the (camera_a, camera_b)-sorted keys so that a camera's own rows are
-  // re-read from that XCD's L2 -- 4.3 -> 5.1 ms on Venice, slower: the interleaved order stays.)
-  for (int64_t key = (int64_t)blockIdx.x * (BLK / 64) + wv; key < nkeys; key += (int64_t)gridDim.x * (BLK / 64)) {
-  const int ca = key_ca[key], cb = key_cb[key];
-  const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
   // element `lane` (< 48) of a task record: J_a[0..23] | J_b camera rows (2 x 9) | Y_b[0..5]
   const int e = lane;
   const int eoff = e < 24 ? e : (e < 33 ? e - 24 + 3 : (e < 42 ? e - 33 + 15 : e - 42));
   d4s acc = {0, 0, 0, 0};
   // Latency hiding inside one wave: task indices come 64 at a time with one coalesced load and are handed out with
-  // v_readlane; the records of the next two task pairs are in flight (registers) while the current pair is multiplied.
+  // v_readlane; the records of the next task pairs are in flight (registers) while the current pair is multiplied.
   for (int c0t = t_begin; c0t < t_end; c0t += 64) {
     const int nin = (t_end - c0t) < 64 ? (t_end - c0t) : 64;
     int my_oa = 0, my_ob = 0;
@@ -341,7 +328,6 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
       if (e < 48) return Y[6 * (int64_t)ob + eoff];
       return 0.0;
     };
-    // SCHUR_PF task pairs in flight per wave (an average key has ~11 tasks: most of a key's records are requested at once)
     double pf[SCHUR_PF][2];
 #pragma unroll
     for (int q = 0; q < SCHUR_PF; q++) {
@@ -358,13 +344,13 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
       pf[SCHUR_PF - 1][0] = fetch(tp + 2 * SCHUR_PF);
       pf[SCHUR_PF - 1][1] = fetch(tp + 2 * SCHUR_PF + 1);
       if (e < 48) {
-        stage[wv][0][e] = ca_v;
-        stage[wv][1][e] = cb_v;
+        stage[0][e] = ca_v;
+        stage[1][e] = cb_v;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const double *sg = stage[wv][tl];
+      const double *sg = stage[tl];
       const bool on = (fr < 9) && (tp + tl < nin);
       const int fi = fr < 9 ? fr : 0;
       const double a0 = sg[12 * al], a1 = sg[12 * al + 1], a2 = sg[12 * al + 2];
@@ -376,22 +362,90 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
       __builtin_amdgcn_wave_barrier();
     }
   }
+  return acc;
+}
+
+// block (ca, cb) of S from the task sum `sum` (element (i, j) per lane as above; i >= 9 or fr >= 9: ignored)
+__device__ inline void schur_store_block(double *S, const int64_t *__restrict__ co, int ca, int cb, const double *__restrict__ Hcc,
+                                         double lambda, const double *__restrict__ damp_c, int i, int j, double sum) {
+  double v = -sum;
+  if (ca == cb) {
+    int hi = i > j ? i : j, lo = i > j ? j : i;
+    v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i == j ? (damp_c ? damp_c[9 * (int64_t)ca + i] : lambda) : 0.0);
+  }
   const int64_t r0 = 9 * (int64_t)ca, c0 = 9 * (int64_t)cb;
-  if (fr < 9) {
+  if (r0 + i >= c0 + j) s_store(S, co, r0 + i, c0 + j, v);
+}
+
+// one wave per key; keys longer than split_above tasks (> 0) are left to k_schur_chunks / k_schur_combine
+__global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *__restrict__ key_ptr,
+                                                       const int *__restrict__ key_ca, const int *__restrict__ key_cb,
+                                                       const int *__restrict__ task_a, const int *__restrict__ task_b,
+                                                       const double *__restrict__ J, const double *__restrict__ Y,
+                                                       const double *__restrict__ Hcc, double lambda,
+                                                       const double *__restrict__ lam_dev, double *__restrict__ S,
+                                                       const int64_t *__restrict__ co, const double *__restrict__ damp_c,
+                                                       int split_above) {
+  __shared__ double stage[BLK / 64][2][48];
+  if (lam_dev) lambda *= lam_dev[0];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  // grid-stride over the keys: the AQL grid size is a 32-bit count of work-items, and Final-13682 has 93.6 M keys
+  // (x 64 lanes > 2^32): a one-wave-per-key launch silently dropped the tail (zero pivots at the first lost diagonal).
+  // (Tried: giving each XCD a contiguous eighth of the (camera_a, camera_b)-sorted keys so that a camera's own rows are
+  // re-read from that XCD's L2 -- 4.3 -> 5.1 ms on Venice, slower: the interleaved order stays.)
+  for (int64_t key = (int64_t)blockIdx.x * (BLK / 64) + wv; key < nkeys; key += (int64_t)gridDim.x * (BLK / 64)) {
+    const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
+    if (split_above > 0 && t_end - t_begin > split_above) continue;
+    const d4s acc = schur_accumulate(t_begin, t_end, task_a, task_b, J, Y, stage[wv]);
+    const int ca = key_ca[key], cb = key_cb[key];
+    if (fr < 9) {
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int i = fk + 4 * g, j = fr;
-      if (i < 9) {
-        double v = -acc[g];
-        if (ca == cb) {
-          int hi = i > j ? i : j, lo = i > j ? j : i;
-          v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i == j ? (damp_c ? damp_c[9 * (int64_t)ca + i] : lambda) : 0.0);
-        }
-        if (r0 + i >= c0 + j) s_store(S, co, r0 + i, c0 + j, v);
+      for (int g = 0; g < 4; g++) {
+        const int i = fk + 4 * g;
+        if (i < 9) schur_store_block(S, co, ca, cb, Hcc, lambda, damp_c, i, fr, acc[g]);
       }
     }
   }
-  }  // key loop
+}
+
+// one wave per chunk of a split key: partial[chunk][i * 9 + j]
+__global__ __launch_bounds__(BLK) void k_schur_chunks(int64_t nchunks, const int *__restrict__ chunk_t0, const int *__restrict__ chunk_t1,
+                                                       const int *__restrict__ task_a, const int *__restrict__ task_b,
+                                                       const double *__restrict__ J, const double *__restrict__ Y,
+                                                       double *__restrict__ partial) {
+  __shared__ double stage[BLK / 64][2][48];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int64_t c = (int64_t)blockIdx.x * (BLK / 64) + wv; c < nchunks; c += (int64_t)gridDim.x * (BLK / 64)) {
+    const d4s acc = schur_accumulate(chunk_t0[c], chunk_t1[c], task_a, task_b, J, Y, stage[wv]);
+    if (fr < 9) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int i = fk + 4 * g;
+        if (i < 9) partial[81 * c + 9 * i + fr] = acc[g];
+      }
+    }
+  }
+}
+
+// one wave per split key: the chunk partials are added in chunk order (fixed) and the block is stored
+__global__ __launch_bounds__(BLK) void k_schur_combine(int64_t nsplit, const int *__restrict__ skey, const int *__restrict__ skey_c0,
+                                                        const int *__restrict__ key_ca, const int *__restrict__ key_cb,
+                                                        const double *__restrict__ partial, const double *__restrict__ Hcc,
+                                                        double lambda, const double *__restrict__ lam_dev, double *__restrict__ S,
+                                                        const int64_t *__restrict__ co, const double *__restrict__ damp_c) {
+  if (lam_dev) lambda *= lam_dev[0];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int64_t q = (int64_t)blockIdx.x * (BLK / 64) + wv; q < nsplit; q += (int64_t)gridDim.x * (BLK / 64)) {
+    const int key = skey[q], c0 = skey_c0[q], c1 = skey_c0[q + 1];
+    const int ca = key_ca[key], cb = key_cb[key];
+    for (int e = lane; e < 81; e += 64) {
+      double sum = 0;
+      for (int c = c0; c < c1; c++) sum += partial[81 * (int64_t)c + e];
+      schur_store_block(S, co, ca, cb, Hcc, lambda, damp_c, e / 9, e % 9, sum);
+    }
+  }
 }
 
 // Column scaling of the reduced camera system (normalize = :J / :A, reference: src/lma_aux.jl:102-154): the reference
@@ -733,9 +787,19 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
   if (T->nkeys > 0) {
     int64_t nb = (T->nkeys + BLK / 64 - 1) / (BLK / 64);
     if (nb > (int64_t)1 << 22) nb = (int64_t)1 << 22;  // 2^22 blocks x 256 lanes = 2^30 work-items
+    const double *damp_c = d_damp ? d_damp + 3 * p->npnts : (const double *)nullptr;
     hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nb), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
-                       T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, d_S, d_col_off,
-                       d_damp ? d_damp + 3 * p->npnts : (const double *)nullptr);
+                       T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, d_S, d_col_off, damp_c,
+                       T->nsplit > 0 ? 2 * T->chunk : 0);
+    if (T->nsplit > 0) {  // long keys: chunk partials, then their fixed-order sums
+      int64_t nbc = (T->nchunks + BLK / 64 - 1) / (BLK / 64), nbs = (T->nsplit + BLK / 64 - 1) / (BLK / 64);
+      if (nbc > (int64_t)1 << 22) nbc = (int64_t)1 << 22;
+      if (nbs > (int64_t)1 << 22) nbs = (int64_t)1 << 22;
+      hipLaunchKernelGGL(k_schur_chunks, dim3((unsigned)nbc), dim3(BLK), 0, st, T->nchunks, T->chunk_t0, T->chunk_t1, T->task_a,
+                         T->task_b, d_J, d_Y, T->partial);
+      hipLaunchKernelGGL(k_schur_combine, dim3((unsigned)nbs), dim3(BLK), 0, st, T->nsplit, T->skey, T->skey_c0, T->key_ca,
+                         T->key_cb, T->partial, d_Hcc, lambda, d_lambda, d_S, d_col_off, damp_c);
+    }
   }
   if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S, d_col_off);
   BA_HIP_CHECK(hipGetLastError());
