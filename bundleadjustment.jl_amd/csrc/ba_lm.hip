@@ -112,8 +112,11 @@ int build_tasks(ba_problem *p, SchurTasks *T) {
   T->nkeys = (int64_t)key_ca.size();
   T->ntasks = ntasks;
   {  // chunking of the long keys (see SchurTasks)
-    int ch = 8;
-    while (ch < 32 && ntasks / ch > 8192 * 4) ch *= 2;
+    // chunk size: the partial blocks cost traffic, so as large as leaves ~8 k chunks for the chip (sweeps on MI355X: LadyBug-49
+    // 4 / 8 / 16 / 32 -> 0.107 / 0.070 / 0.058 / 0.065 ms; Dubrovnik-356 8 / 32 / 128 / 256 -> 1.12 / 0.68 / 0.58 / 0.57 ms
+    // (unsplit: 2.26); Venice-1778 unsplit / 8 / 32 / 128 -> 4.36 / 4.02 / 3.52 / 3.42 ms)
+    int ch = 16;
+    while (ch < 128 && ntasks / (2 * ch) >= 8192) ch *= 2;
     if (const char *e = getenv("BA_SCHUR_CHUNK")) ch = atoi(e);  // 0 disables the split
     T->chunk = ch;
     std::vector<int> skey, skey_c0, ct0, ct1;
