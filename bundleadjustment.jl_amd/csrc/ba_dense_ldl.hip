@@ -1269,6 +1269,10 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
   BA_HIP_CHECK(hipMalloc((void **)&w->ready, (size_t)nt * sizeof(int)));
   BA_HIP_CHECK(hipStreamCreateWithFlags(&w->hoist, hipStreamNonBlocking));
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_top, hipEventDisableTiming | hipEventReleaseToDevice));
+  for (int q = 0; q < 2; q++) {
+    BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_recv[q], hipEventDisableTiming));
+    BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_upd[q], hipEventDisableTiming));
+  }
   return set_kernel_attrs<T>();
 }
 
@@ -1287,6 +1291,10 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->hoist) (void)hipStreamDestroy(w->hoist);
   if (w->ev_top) (void)hipEventDestroy(w->ev_top);
   if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
+  for (int q = 0; q < 2; q++) {
+    if (w->ev_recv[q]) (void)hipEventDestroy(w->ev_recv[q]);
+    if (w->ev_upd[q]) (void)hipEventDestroy(w->ev_upd[q]);
+  }
   *w = DenseLDLT<T>();
 }
 
@@ -1457,18 +1465,57 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
   return BA_OK;
 }
 
-// pair update restricted to the tile columns >= base that this rank owns
+// pair update (panels k, k+1) of the owned tile columns own_cols[m0 .. m1)
 template <typename T>
-static int launch_pair_owned(ba_problem *p, DenseLDLT<T> *w, int k, int base, const T *V0, const T *V1, hipStream_t st) {
-  const int M = (int)w->h_own_cols.size();
-  const int m0 = (int)(std::lower_bound(w->h_own_cols.begin(), w->h_own_cols.end(), base) - w->h_own_cols.begin());
-  if (m0 >= M) return BA_OK;
-  const int64_t nblk64 = w->h_own_pref[(size_t)M] - w->h_own_pref[(size_t)m0];
+static int launch_pair_owned(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0, const T *V1, hipStream_t st, int m0, int m1) {
+  if (m0 >= m1) return BA_OK;
+  const int64_t nblk64 = w->h_own_pref[(size_t)m1] - w->h_own_pref[(size_t)m0];
   if (nblk64 <= 0) return BA_OK;
   const int nblk = (int)nblk64;
   ProfScope ps(p, PC_LDL_UPDATE, st);
   hipLaunchKernelGGL((k_ldl_update<T, 1, 0, true>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st,
-                     w->S, w->col_off, V0, V1, k, base, (int)w->nt, nblk, (int *)nullptr, w->own_cols, w->own_pref, m0, M);
+                     w->S, w->col_off, V0, V1, k, w->h_own_cols[(size_t)m0], (int)w->nt, nblk, (int *)nullptr, w->own_cols, w->own_pref, m0, m1);
+  return BA_OK;
+}
+
+// the panel chain of pair (k, k+1) on its owner (dense_ldl_factor's in-order chain, no right-hand side)
+template <typename T>
+static int dist_chain(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *V1, hipStream_t st) {
+  launch_diag(p, w, k, st);
+  launch_trsm(p, w, k, V0, (T *)nullptr, st);
+  if (k + 1 < (int)w->nt) {
+    launch_col(p, w, k, V0, st);
+    launch_diag(p, w, k + 1, st);
+    launch_trsm(p, w, k + 1, V1, (T *)nullptr, st);
+  }
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+// pair (k, k+1) from its owner to everybody: V = L D of both panels, the two inverted diagonal tiles, the 256 pivots (one
+// grouped broadcast); the receivers rebuild L = V D^-1 in their copy of S
+template <typename T>
+static int dist_transfer(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *V1, int owner, hipStream_t st) {
+  const int nt = (int)w->nt;
+  const bool two = k + 1 < nt;
+  const int rows0 = nt - k - 1, rows1 = nt - k - 2;  // tile rows below the diagonal tile of column k / k + 1
+  BA_CHECK(comm_group_begin(p));
+  int rc = BA_OK;
+  if (rows0 > 0) rc = comm_bcast(p, V0 + (int64_t)(k + 1) * NB * NB, (int64_t)rows0 * NB * NB * sizeof(T), owner, st);
+  if (rc == BA_OK && two && rows1 > 0)
+    rc = comm_bcast(p, V1 + (int64_t)(k + 2) * NB * NB, (int64_t)rows1 * NB * NB * sizeof(T), owner, st);
+  if (rc == BA_OK) rc = comm_bcast(p, w->Linv + (int64_t)k * NB * NB, (int64_t)(two ? 2 : 1) * NB * NB * sizeof(T), owner, st);
+  if (rc == BA_OK) rc = comm_bcast(p, w->D + (int64_t)k * NB, (int64_t)(two ? 2 : 1) * NB * sizeof(T), owner, st);
+  BA_CHECK(comm_group_end(p));
+  BA_CHECK(rc);
+  if (owner != w->rank) {
+    if (rows0 > 0)
+      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows0), dim3(256), 0, st, w->S, w->col_off, V0, w->D + (int64_t)k * NB, k, k + 1);
+    if (two && rows1 > 0)
+      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows1), dim3(256), 0, st, w->S, w->col_off, V1, w->D + (int64_t)(k + 1) * NB,
+                         k + 1, k + 2);
+    BA_HIP_CHECK(hipGetLastError());
+  }
   return BA_OK;
 }
 
@@ -1479,6 +1526,16 @@ static int launch_pair_owned(ba_problem *p, DenseLDLT<T> *w, int k, int base, co
 // whole factor, so the triangular solves are replicated and bit-identical everywhere.  Traffic per rank: the panels,
 // n^2/2 elements in total (Venice, n = 16 002: 1.0 GB; Final-13682, n = 123 138: 60 GB Float64 / 30 GB Float32) against
 // n^3/(3 world) flops.  The hoisted-diagonal schedule is a single-GPU refinement and is not used here.
+//
+// Look-ahead of one pair (default; BA_DIST_LOOKAHEAD=0 gives the strictly alternating chain / broadcast / update): the
+// owner of pair q+1 applies pair q's update to ITS two leading tile columns first, runs the chain of pair q+1 at once and
+// hands the panels to the transfer stream, then finishes its share of update q; everybody else receives pair q+1 on the
+// transfer stream while update q runs.  Chain and broadcast of pair q+1 thus hide behind update q wherever that update is
+// the longer of the two (Final-13682 on 8 ranks: 2.4 ms of update per pair and rank against ~0.7 ms of chain and ~2 ms of
+// broadcast).  The arithmetic -- which tile receives which products in which order -- is that of the alternating
+// schedule: the results are bit-identical (tests/test_distributed.py).  Buffers: pair q's panels live in Vs[q & 1];
+// transfer q+1 may overwrite Vs[(q+1) & 1] only when update q-1 is through with it (ev_upd), update q+1 starts when
+// transfer q+1 has landed (ev_recv).
 template <typename T>
 int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
   const int nt = (int)w->nt, P = w->world, me = w->rank;
@@ -1486,39 +1543,52 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
   T *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
   BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
   w->hoisting = false;
-  for (int k = 0, q = 0; k < nt; k += 2, q++) {
-    T *V0 = Vs[q & 1][0], *V1 = Vs[q & 1][1];
-    const int owner = q % P;
-    const bool two = k + 1 < nt;
-    if (owner == me) {
-      launch_diag(p, w, k, st);
-      launch_trsm(p, w, k, V0, (T *)nullptr, st);
-      if (two) {
-        launch_col(p, w, k, V0, st);
-        launch_diag(p, w, k + 1, st);
-        launch_trsm(p, w, k + 1, V1, (T *)nullptr, st);
+  static const bool la_off = [] { const char *e = getenv("BA_DIST_LOOKAHEAD"); return e && e[0] == '0'; }();
+  const int M = (int)w->h_own_cols.size();
+  auto own_from = [&](int base) {  // index of the first owned tile column >= base
+    return (int)(std::lower_bound(w->h_own_cols.begin(), w->h_own_cols.end(), base) - w->h_own_cols.begin());
+  };
+  if (la_off || p->prof_on) {  // (per-kernel profiling times one launch at a time: nothing could overlap)
+    for (int k = 0, q = 0; k < nt; k += 2, q++) {
+      T *V0 = Vs[q & 1][0], *V1 = Vs[q & 1][1];
+      const int owner = q % P;
+      if (owner == me) BA_CHECK(dist_chain(p, w, k, V0, V1, st));
+      BA_CHECK(dist_transfer(p, w, k, V0, V1, owner, st));
+      if (k + 2 >= nt) break;
+      BA_CHECK(launch_pair_owned(p, w, k, V0, V1, st, own_from(k + 2), M));
+    }
+  } else {
+    hipStream_t cs = w->hoist;  // transfer stream
+    BA_HIP_CHECK(hipEventRecord(w->ev_top, st));  // fork: behind the reduce of S
+    BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_top, 0));
+    if (0 % P == me) {
+      BA_CHECK(dist_chain(p, w, 0, Vs[0][0], Vs[0][1], st));
+      BA_HIP_CHECK(hipEventRecord(w->ev_chain, st));
+      BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_chain, 0));
+    }
+    BA_CHECK(dist_transfer(p, w, 0, Vs[0][0], Vs[0][1], 0, cs));
+    BA_HIP_CHECK(hipEventRecord(w->ev_recv[0], cs));
+    for (int k = 0, q = 0; k < nt; k += 2, q++) {
+      T *V0 = Vs[q & 1][0], *V1 = Vs[q & 1][1];
+      T *N0 = Vs[(q + 1) & 1][0], *N1 = Vs[(q + 1) & 1][1];
+      BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_recv[q & 1], 0));  // pair q's panels are here (join of the transfer stream)
+      if (k + 2 >= nt) break;
+      const bool next_mine = (q + 1) % P == me;
+      int m0 = own_from(k + 2);
+      if (next_mine) {  // tile columns k+2 [, k+3] are mine and come first in the owned list
+        const int lead = (k + 3 < nt) ? 2 : 1;
+        BA_CHECK(launch_pair_owned(p, w, k, V0, V1, st, m0, m0 + lead));
+        BA_CHECK(dist_chain(p, w, k + 2, N0, N1, st));
+        BA_HIP_CHECK(hipEventRecord(w->ev_chain, st));
+        m0 += lead;
       }
+      BA_CHECK(launch_pair_owned(p, w, k, V0, V1, st, m0, M));
+      BA_HIP_CHECK(hipEventRecord(w->ev_upd[q & 1], st));
+      if (q >= 1) BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_upd[(q + 1) & 1], 0));  // update q-1 has read Vs[(q+1)&1]
+      if (next_mine) BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_chain, 0));
+      BA_CHECK(dist_transfer(p, w, k + 2, N0, N1, (q + 1) % P, cs));
+      BA_HIP_CHECK(hipEventRecord(w->ev_recv[(q + 1) & 1], cs));
     }
-    BA_HIP_CHECK(hipGetLastError());
-    const int rows0 = nt - k - 1, rows1 = nt - k - 2;  // tile rows below the diagonal tile of column k / k + 1
-    BA_CHECK(comm_group_begin(p));
-    int rc = BA_OK;
-    if (rows0 > 0) rc = comm_bcast(p, V0 + (int64_t)(k + 1) * NB * NB, (int64_t)rows0 * NB * NB * sizeof(T), owner, st);
-    if (rc == BA_OK && two && rows1 > 0)
-      rc = comm_bcast(p, V1 + (int64_t)(k + 2) * NB * NB, (int64_t)rows1 * NB * NB * sizeof(T), owner, st);
-    if (rc == BA_OK) rc = comm_bcast(p, w->Linv + (int64_t)k * NB * NB, (int64_t)(two ? 2 : 1) * NB * NB * sizeof(T), owner, st);
-    if (rc == BA_OK) rc = comm_bcast(p, w->D + (int64_t)k * NB, (int64_t)(two ? 2 : 1) * NB * sizeof(T), owner, st);
-    BA_CHECK(comm_group_end(p));
-    BA_CHECK(rc);
-    if (owner != me) {
-      if (rows0 > 0)
-        hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows0), dim3(256), 0, st, w->S, w->col_off, V0, w->D + (int64_t)k * NB, k, k + 1);
-      if (two && rows1 > 0)
-        hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows1), dim3(256), 0, st, w->S, w->col_off, V1, w->D + (int64_t)(k + 1) * NB,
-                           k + 1, k + 2);
-    }
-    if (k + 2 >= nt) break;
-    BA_CHECK(launch_pair_owned(p, w, k, k + 2, V0, V1, st));
   }
   // an exactly zero pivot is seen by the owner of that tile only: make the flag collective
   hipLaunchKernelGGL(k_flag_to_double, dim3(1), dim3(1), 0, st, w->flag, w->flag_sum);

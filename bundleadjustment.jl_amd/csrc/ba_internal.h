@@ -88,6 +88,8 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   bool hoisting = false;         // the factorisation forks onto `hoist` (set by dense_ldl_factor's schedule choice)
   bool own_S = true;
   hipEvent_t ev_chain = nullptr;  // recorded behind each hoisted diagonal kernel
+  // distributed factorisation with look-ahead: panels of pair q received (transfer stream), update of pair q launched
+  hipEvent_t ev_recv[2] = {nullptr, nullptr}, ev_upd[2] = {nullptr, nullptr};
 };
 typedef DenseLDLT<double> DenseLDL;
 

@@ -35,6 +35,23 @@ def main():
             out["half_" + tag] = float(abs(half - half_ref) / half_ref)
             out["jtr_" + tag] = float(np.max(np.abs(jtr - jtr_ref)) / np.max(np.abs(jtr_ref)))
         bf.close()
+    # (a2) 8 tile column pairs (200 cameras: n = 1800, 15 tile rows): the look-ahead's two-deep panel buffers are reused
+    # several times; the gathered step travels to the test, which compares the look-ahead run with the alternating one
+    wide = ba.synthetic.make_problem(200, 1500, 9000, seed=11)
+    warr = ba.synthetic.as_arrays(wide)
+    wl, winfo = ba.parallel.shard_problem(warr, rank, world)
+    wn = ba.BALNLPModel(arrays=wl, device=0)
+    ba.parallel.CameraBlockReducer(wn)
+    dw, halfw, _ = ba.lm_step(wn, wl[3], 10.0)
+    dw = ba.parallel.gather_solution(dw, winfo, wide["ncams"])
+    wn.close()
+    if rank == 0:
+        wf = ba.BALNLPModel(arrays=warr, device=0)
+        dw_ref, halfw_ref, _ = ba.lm_step(wf, warr[3], 10.0)
+        wf.close()
+        out["step_wide"] = float(np.linalg.norm(dw - dw_ref) / np.linalg.norm(dw_ref))
+        out["half_wide"] = float(abs(halfw - halfw_ref) / halfw_ref)
+        out["wide_hex"] = [float(v).hex() for v in dw[-9 * wide["ncams"]:]]
     # (b) complete LM runs
     prob = ba.synthetic.make_problem(14, 600, 2700, seed=5)
     arrays = ba.synthetic.as_arrays(prob)

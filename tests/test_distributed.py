@@ -66,6 +66,7 @@ def _check_sharded(res):
     # order only; Float32 factorisation: Float32 level)
     assert res["step_f64"] <= 1e-9 and res["half_f64"] <= 1e-10 and res["jtr_f64"] <= 1e-12
     assert res["step_f32"] <= 5e-3 and res["jtr_f32"] <= 1e-12
+    assert res["step_wide"] <= 1e-9 and res["half_wide"] <= 1e-10
     assert res["step_calls"] > 0
     assert res["iter"] == res["ref_iter"] and res["status"] == res["ref_status"] and res["log_equal"]
     assert abs(res["objective"] - res["ref_objective"]) <= 1e-9 * res["ref_objective"]
@@ -84,6 +85,21 @@ def test_sharded_lm_ranks_share_one_gpu(tmp_path, gpu_ok, nproc):
     """2 and 3 ranks (gloo, hook transport) on cuda:0: observations sharded by point, reduced camera matrix reduced onto
     the owners of its tile column pairs, factorisation distributed, solves replicated -- must reproduce the one-rank run."""
     _check_sharded(_run_ranks("sharded_lm_gpu.py", nproc, tmp_path))
+
+
+@pytest.mark.gpu
+def test_dist_lookahead_equals_alternating_schedule(tmp_path, gpu_ok):
+    """The distributed factorisation with look-ahead (owner of the next pair updates its leading columns first, runs its
+    chain and broadcasts beside the rest of the update) does the same arithmetic as the strictly alternating schedule
+    (BA_DIST_LOOKAHEAD=0): the camera part of the step is bit-identical on 3 ranks."""
+    a = _run_ranks("sharded_lm_gpu.py", 3, tmp_path)
+    os.environ["BA_DIST_LOOKAHEAD"] = "0"
+    try:
+        b = _run_ranks("sharded_lm_gpu.py", 3, tmp_path)
+    finally:
+        del os.environ["BA_DIST_LOOKAHEAD"]
+    _check_sharded(b)
+    assert a["wide_hex"] == b["wide_hex"]
 
 
 @pytest.mark.gpu
@@ -112,6 +128,10 @@ def test_rccl_single_rank(ba, small_prob, gpu_ok):
     bref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(big))
     d_ref, half_ref, _ = ba.lm_step(bref, big["x0"], 25.0)
     bref.close()
+    wide = ba.synthetic.make_problem(200, 1500, 9000, seed=11)  # 15 tile rows: 8 pairs through the look-ahead's buffers
+    wref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(wide))
+    dw_ref, halfw_ref, _ = ba.lm_step(wref, wide["x0"], 10.0)
+    wref.close()
     torch.cuda.set_device(0)
     torch.zeros(1, device="cuda")  # initialise torch's HIP context before c10d counts the devices
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -131,6 +151,12 @@ def test_rccl_single_rank(ba, small_prob, gpu_ok):
         d, half, _ = ba.lm_step(bm, big["x0"], 25.0)
         assert np.linalg.norm(d - d_ref) <= 1e-10 * np.linalg.norm(d_ref) and abs(half - half_ref) <= 1e-11 * half_ref
         bm.close()
+        wm = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(wide))
+        ba.parallel.CameraBlockReducer(wm)
+        for _ in range(2):  # twice: the second factorisation re-uses events and panel buffers of the first
+            dw, halfw, _ = ba.lm_step(wm, wide["x0"], 10.0)
+            assert np.linalg.norm(dw - dw_ref) <= 1e-10 * np.linalg.norm(dw_ref) and abs(halfw - halfw_ref) <= 1e-11 * halfw_ref
+        wm.close()
     finally:
         dist.destroy_process_group()
     ref.close()
