@@ -181,6 +181,26 @@ def main():
     jac_bytes = (208.0 + 8.0 * nvar_g / nobs_g) * nobs_g / world
     jac_gbs = jac_bytes / (jac_ms * 1e-3) / 1e9
 
+    # ---- residual throughput (cons!): the same way; one launch = k_cam_pre (a few us) + k_residual --------------------------
+    r_dev = torch.empty(2 * nlp.nobs, dtype=torch.float64, device="cuda")
+
+    def res():
+        ba._lib.check(L.ba_residual_dev(nlp.handle, C.c_void_p(x_dev.data_ptr()), C.c_void_p(r_dev.data_ptr()), sp))
+
+    for _ in range(3):
+        res()
+    barrier()
+    e0.record(stream)
+    for _ in range(reps):
+        res()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    res_ms = max_over_ranks(e0.elapsed_time(e1) / reps)
+    # algorithmic bytes of cons!: 2 int64 indices + 2 doubles of pt2d + 2 doubles out + every parameter once
+    res_bytes = (48.0 + 8.0 * nvar_g / nobs_g) * nobs_g / world
+    res_gbs = res_bytes / (res_ms * 1e-3) / 1e9
+    del r_dev
+
     # ---- per-kernel profile of the same K iterations (separate, synchronising run) ---------------------------------------
     prof = {}
     if not args.no_profile:
@@ -210,6 +230,9 @@ def main():
                     frac=jac_gbs / HBM_PEAK_GBS, traffic=None if jac_traffic is None else jac_traffic / world,
                     avg_launch_ms=jac_ms,
                     bytes_per_obs=208.0 + 8.0 * nvar_g / nobs_g)
+    roof_res = dict(kernel="k_cam_pre + k_residual", bound="hbm", achieved=res_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=res_gbs / HBM_PEAK_GBS, traffic=None, avg_launch_ms=res_ms,
+                    bytes_per_obs=48.0 + 8.0 * nvar_g / nobs_g)
     if roof is None:
         roof = roof_jac
 
@@ -304,6 +327,7 @@ def main():
                    "n_jacobian": st.n_jacobian, "n_factor": st.n_factor, "loop_s": st.loop_time},
             "roofline": roof,
             "roofline_jacobian": roof_jac,
+            "roofline_residual": roof_res,
             "cpu_baseline": cpu,
             "cpu_baseline_full": cpu_full,
             "kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1] > 0},

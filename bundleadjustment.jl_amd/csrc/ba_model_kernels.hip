@@ -33,54 +33,6 @@ struct Trig<float> {
   static __device__ inline float sq(float v) { return sqrtf(v); }
 };
 
-// projection!  src/BALNLPModels.jl:17-33 in the reference's evaluation order (left folds).
-// P1 is returned too (the Jacobian needs it).  No theta->0 / z==0 guards: the reference has none.
-template <typename T>
-__device__ inline void project(const T X[3], const T C[9], T P1[3], T P2[2], T out[2], T &th, T &s, T &c,
-                               T k[3], T &d) {
-  th = Trig<T>::sq(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
-  k[0] = C[0] / th;
-  k[1] = C[1] / th;
-  k[2] = C[2] / th;
-  Trig<T>::sc(th, s, c);
-  T kx0 = k[1] * X[2] - k[2] * X[1];
-  T kx1 = k[2] * X[0] - k[0] * X[2];
-  T kx2 = k[0] * X[1] - k[1] * X[0];
-  d = k[0] * X[0] + k[1] * X[1] + k[2] * X[2];
-  T omc_d = (1 - c) * d;
-  P1[0] = ((c * X[0] + s * kx0) + omc_d * k[0]) + C[3];
-  P1[1] = ((c * X[1] + s * kx1) + omc_d * k[1]) + C[4];
-  P1[2] = ((c * X[2] + s * kx2) + omc_d * k[2]) + C[5];
-  P2[0] = -P1[0] / P1[2];
-  P2[1] = -P1[1] / P1[2];
-  T sqn = P2[0] * P2[0] + P2[1] * P2[1];
-  // scaling_factor: the literal 1.0 is a Float64 (BALNLPModels.jl:13) -> promoted for T = Float32
-  double sc = (1.0 + (double)(C[6] * sqn)) + (double)(C[7] * (sqn * sqn));
-  double fs = (double)C[8] * sc;
-  out[0] = (T)(fs * (double)P2[0]);
-  out[1] = (T)(fs * (double)P2[1]);
-}
-
-template <typename T>
-__global__ __launch_bounds__(BLK) void k_residual(int64_t nobs, int64_t npnts, const int *__restrict__ cam0,
-                                                   const int *__restrict__ pnt0, const T *__restrict__ x,
-                                                   const T *__restrict__ pt2d, T *__restrict__ r) {
-  int64_t o = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  if (o >= nobs) return;
-  const T *Xp = x + 3 * (int64_t)pnt0[o];
-  const T *Cp = x + 3 * npnts + 9 * (int64_t)cam0[o];
-  T X[3], C[9];
-#pragma unroll
-  for (int i = 0; i < 3; i++) X[i] = Xp[i];
-#pragma unroll
-  for (int i = 0; i < 9; i++) C[i] = Cp[i];
-  T P1[3], P2[2], out[2], th, s, c, k[3], d;
-  project<T>(X, C, P1, P2, out, th, s, c, k, d);
-  // cx .-= pt2d  (BALNLPModels.jl:118)
-  r[2 * o] = out[0] - pt2d[2 * o];
-  r[2 * o + 1] = out[1] - pt2d[2 * o + 1];
-}
-
 // jac_structure!  BALNLPModels.jl:125-158.  One lane writes two consecutive entries (16 B) of rows and of cols.
 __global__ __launch_bounds__(BLK) void k_jac_structure(int64_t nobs, int64_t npnts, const int *__restrict__ cam0,
                                                         const int *__restrict__ pnt0, int64_t *__restrict__ rows,
@@ -114,19 +66,45 @@ __global__ __launch_bounds__(BLK) void k_jac_structure(int64_t nobs, int64_t npn
 //   [kx ky kz | t(3) | k1 k2 f | sin cos 1/theta | 0 0 0 0]
 template <typename T>
 __device__ inline void cam_pre(const T C[9], T P[12]) {
-#pragma clang fp contract(fast)
+  // theta, the axis, sin and cos in the reference's operation order (BALNLPModels.jl:19-22: sqrt of the left-folded sum,
+  // three divisions, no contraction; no theta -> 0 guard: the reference has none): the residual takes them from this
+  // row, and evaluating them once per camera instead of once per observation changes no bit.  1/theta is for the
+  // Jacobian only.
   const T th = Trig<T>::sq(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
-  const T ith = (T)1 / th;
   T s, c;
   Trig<T>::sc(th, s, c);
-  P[0] = C[0] * ith;
-  P[1] = C[1] * ith;
-  P[2] = C[2] * ith;
+  P[0] = C[0] / th;
+  P[1] = C[1] / th;
+  P[2] = C[2] / th;
 #pragma unroll
   for (int i = 3; i < 9; i++) P[i] = C[i];
   P[9] = s;
   P[10] = c;
-  P[11] = ith;
+  P[11] = (T)1 / th;
+}
+
+// projection!  src/BALNLPModels.jl:17-33 from a cam_pre row, in the reference's evaluation order (left folds; no z == 0
+// guard: the reference has none).  scaling_factor: the literal 1.0 is a Float64 (BALNLPModels.jl:13) -> promoted for
+// T = Float32.
+template <typename T>
+__device__ inline void project_pre(const T X[3], const T P[12], T out[2]) {
+  const T k0 = P[0], k1 = P[1], k2 = P[2], s = P[9], c = P[10];
+  T kx0 = k1 * X[2] - k2 * X[1];
+  T kx1 = k2 * X[0] - k0 * X[2];
+  T kx2 = k0 * X[1] - k1 * X[0];
+  T d = k0 * X[0] + k1 * X[1] + k2 * X[2];
+  T omc_d = (1 - c) * d;
+  T P1[3], P2[2];
+  P1[0] = ((c * X[0] + s * kx0) + omc_d * k0) + P[3];
+  P1[1] = ((c * X[1] + s * kx1) + omc_d * k1) + P[4];
+  P1[2] = ((c * X[2] + s * kx2) + omc_d * k2) + P[5];
+  P2[0] = -P1[0] / P1[2];
+  P2[1] = -P1[1] / P1[2];
+  T sqn = P2[0] * P2[0] + P2[1] * P2[1];
+  double sc = (1.0 + (double)(P[6] * sqn)) + (double)(P[7] * (sqn * sqn));
+  double fs = (double)P[8] * sc;
+  out[0] = (T)(fs * (double)P2[0]);
+  out[1] = (T)(fs * (double)P2[1]);
 }
 
 template <typename T>
@@ -462,6 +440,64 @@ __global__ __launch_bounds__(BLK) void k_jac_coord(int64_t nobs, int64_t npnts, 
   }
 }
 
+// cons!: one lane per observation.  Everything that depends on the camera alone (theta, axis, sin, cos: a square root,
+// three divisions and a sincos) comes from the cam_pre row of the camera, computed once per camera by k_cam_pre at this x,
+// and the rows reach the lanes the way k_jac_coord's do: eight (four) lanes fetch one observation's 128-byte (64-byte)
+// row as aligned 16-byte pieces -- a full line per observation and instruction -- and hand it over through the wave's LDS
+// slot.  The first version (nine scattered 8-byte loads and the whole trigonometric chain per lane) ran at 31 % of the
+// HBM roofline on Venice.
+// RNB batches of 64 observations per wave, straight-line: all index, point and row requests of the wave are issued before
+// the first batch is evaluated.  Venice (5.0 M observations), rocprofv3: 91.9 us for the first version, 56.6-60.0 us with
+// one batch per wave, 54.8-57.4 us with two (shipped), 77 us with four (registers); what bounds it now is the L1's
+// request path (per 64 observations: 8 row instructions of 1 KB each beside 7 others), not HBM.
+template <typename T, int RNB>
+__global__ __launch_bounds__(BLK) void k_residual(int64_t nobs, const int *__restrict__ cam0, const int *__restrict__ pnt0,
+                                                   const T *__restrict__ x, const T *__restrict__ cpre,
+                                                   const T *__restrict__ pt2d, T *__restrict__ r) {
+  typedef CamStage<T> S;
+  typedef T v2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) unsigned slot[BLK / 64][64 * S::CSTR];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t base = ((int64_t)blockIdx.x * (BLK / 64) + wv) * (64 * RNB) + lane;
+  const int piece = lane % S::LPO, sub = lane / S::LPO;
+  int ci[RNB], pi[RNB];
+  v2 m[RNB];
+  T X[RNB][3];
+  typename S::vt stg[RNB][S::NI];
+#pragma unroll
+  for (int b = 0; b < RNB; b++) {
+    const int64_t o = base + 64 * b;
+    const int64_t oc = o < nobs ? o : nobs - 1;  // lanes past the end shadow the last observation (their rows are still fetched)
+    ci[b] = cam0[oc];
+    pi[b] = pnt0[oc];
+    m[b] = *reinterpret_cast<const v2 *>(pt2d + 2 * oc);
+  }
+#pragma unroll
+  for (int b = 0; b < RNB; b++) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) X[b][i] = x[3 * (int64_t)pi[b] + i];
+#pragma unroll
+    for (int j = 0; j < S::NI; j++) {
+      const int c = __shfl(ci[b], j * S::OPI + sub, 64);
+      // (every lane loads, the pieces past the data too: under a per-lane condition the requests serialise -- 165 us)
+      stg[b][j] = *(reinterpret_cast<const typename S::vt *>(cpre + CPAD * (int64_t)c) + piece);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < RNB; b++) {
+    T P[12], out[2];
+    jac_land_cam<T>(stg[b], lane, reinterpret_cast<T *>(slot[wv]), P);
+    project_pre<T>(X[b], P, out);
+    const int64_t o = base + 64 * b;
+    if (o < nobs) {  // cx .-= pt2d  (BALNLPModels.jl:118)
+      v2 res;
+      res[0] = out[0] - m[b][0];
+      res[1] = out[1] - m[b][1];
+      *reinterpret_cast<v2 *>(r + 2 * o) = res;
+    }
+  }
+}
+
 }  // namespace
 
 static inline unsigned grid_for(int64_t n, int blk) { return (unsigned)((n + blk - 1) / blk); }
@@ -493,8 +529,12 @@ static unsigned jac_grid(ba_problem *p, K kernel, int64_t nobs) {
 int launch_residual_f64(ba_problem *p, const double *d_x, double *d_r, hipStream_t st) {
   if (p->nobs == 0) return BA_OK;
   ProfScope ps(p, PC_RESIDUAL, st);
-  hipLaunchKernelGGL(k_residual<double>, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0,
-                     p->pnt0, d_x, p->pt2d, d_r);
+  double *cpad = nullptr;
+  BA_CHECK(ba_scratch(p, 3, (size_t)(p->ncams * CPAD + 2) * sizeof(double), (void **)&cpad));
+  hipLaunchKernelGGL(k_cam_pre<double>, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_x + 3 * p->npnts,
+                     cpad);
+  hipLaunchKernelGGL((k_residual<double, 2>), dim3(grid_for(p->nobs, BLK * 2)), dim3(BLK), 0, st, p->nobs, p->cam0, p->pnt0, d_x,
+                     (const double *)cpad, p->pt2d, d_r);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
@@ -502,8 +542,11 @@ int launch_residual_f64(ba_problem *p, const double *d_x, double *d_r, hipStream
 int launch_residual_f32(ba_problem *p, const float *d_x, float *d_r, hipStream_t st) {
   if (p->nobs == 0) return BA_OK;
   ProfScope ps(p, PC_RESIDUAL, st);
-  hipLaunchKernelGGL(k_residual<float>, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0,
-                     p->pnt0, d_x, p->pt2d_f32, d_r);
+  float *cpad = nullptr;
+  BA_CHECK(ba_scratch(p, 3, (size_t)(p->ncams * CPAD + 2) * sizeof(double), (void **)&cpad));
+  hipLaunchKernelGGL(k_cam_pre<float>, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_x + 3 * p->npnts, cpad);
+  hipLaunchKernelGGL((k_residual<float, 2>), dim3(grid_for(p->nobs, BLK * 2)), dim3(BLK), 0, st, p->nobs, p->cam0, p->pnt0, d_x,
+                     (const float *)cpad, p->pt2d_f32, d_r);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
