@@ -69,6 +69,24 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   }
   launch();
   BA_HIP_CHECK(hipDeviceSynchronize());
+  if (getenv("BA_BENCH_PERREP")) {  // every launch timed by its own event pair: drift of the rate under sustained load
+    std::vector<hipEvent_t> ev((size_t)reps + 1);
+    for (auto &e : ev) BA_HIP_CHECK(hipEventCreate(&e));
+    BA_HIP_CHECK(hipEventRecord(ev[0], 0));
+    for (int r = 0; r < reps; r++) {
+      launch();
+      BA_HIP_CHECK(hipEventRecord(ev[(size_t)r + 1], 0));
+    }
+    BA_HIP_CHECK(hipEventSynchronize(ev[(size_t)reps]));
+    fprintf(stderr, "[perrep]");
+    for (int r = 0; r < reps; r++) {
+      float t = 0;
+      BA_HIP_CHECK(hipEventElapsedTime(&t, ev[(size_t)r], ev[(size_t)r + 1]));
+      fprintf(stderr, " %.3f", t);
+    }
+    fprintf(stderr, "\n");
+    for (auto &e : ev) (void)hipEventDestroy(e);
+  }
   BA_HIP_CHECK(hipEventRecord(e0, 0));
   for (int r = 0; r < reps; r++) launch();
   BA_HIP_CHECK(hipEventRecord(e1, 0));

@@ -11,5 +11,5 @@ m = nt - 2
 flops = m * (m + 1) / 2 * 2 * 128 * 128 * 256
 for v in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 1, 2, 8, 9, 16, 17, 0, 16)):
     ms = C.c_double(0)
-    rc = L.ba_debug_update_bench(nt, v, 5, C.byref(ms))
+    rc = L.ba_debug_update_bench(nt, v, int(os.environ.get('BA_BENCH_REPS', '5')), C.byref(ms))
     print(f"variant {v}: {ms.value:.3f} ms  {flops / ms.value / 1e9:.1f} TFLOP/s (rc {rc})", flush=True)
