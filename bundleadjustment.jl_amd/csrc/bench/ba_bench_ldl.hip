@@ -1,6 +1,7 @@
 // Bench-only entry points of the dense LDL' kernels (tools/bench_update.py, bench_diag.py, bench_mfma_probe.py): built into
 // tools/libba_bench.so, NOT into libba_hip.so.  This translation unit includes the product source so that the probes
 // time the very kernels that ship.
+#include <time.h>
 #include "../ba_dense_ldl.hip"
 
 namespace {
@@ -94,6 +95,57 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   float ms = 0;
   BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   *ms_out = ms / reps;
+  (void)hipFree(S);
+  (void)hipFree(V);
+  (void)hipFree(co);
+  return BA_OK;
+}
+
+// a sequence of pair updates of m_list[q] tile rows each on one nt x nt tile matrix (nonzero operands), every launch
+// timed by its own event pair; gap_us[q] > 0: the host sleeps that long BEFORE launch q (tools/bench_update_seq.py)
+extern "C" int ba_debug_update_seq(int nt, int n, const int *m_list, const int *gap_us, double *ms_out) {
+  BA_CHECK(set_bench_kernel_attrs());
+  const size_t tiles = (size_t)nt * (nt + 1) / 2 * NB * NB, vel = (size_t)2 * nt * NB * NB;
+  double *S = nullptr, *V = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&S, tiles * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&V, vel * sizeof(double)));
+  hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, 0, S, tiles, 1e-3);
+  hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((vel + 255) / 256)), dim3(256), 0, 0, V, vel, 1e-3);
+  std::vector<int64_t> h_co;
+  dense_ldl_layout(nt, 1, &h_co, nullptr);
+  int64_t *co = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&co, (size_t)nt * sizeof(int64_t)));
+  BA_HIP_CHECK(hipMemcpy(co, h_co.data(), (size_t)nt * sizeof(int64_t), hipMemcpyHostToDevice));
+  std::vector<hipEvent_t> ev((size_t)2 * n);
+  for (auto &e : ev) BA_HIP_CHECK(hipEventCreate(&e));
+  BA_HIP_CHECK(hipDeviceSynchronize());
+  const double *V0 = V, *V1 = V + (size_t)nt * NB * NB;
+  for (int q = 0; q < n; q++) {
+    if (gap_us && gap_us[q] > 0) {
+      BA_HIP_CHECK(hipDeviceSynchronize());
+      timespec ts = {0, (long)gap_us[q] * 1000};
+      nanosleep(&ts, nullptr);
+    }
+    if (m_list[q] < 0) {  // -c: c passes of a memory-bound kernel over S (what precedes a factorisation in the LM loop)
+      BA_HIP_CHECK(hipEventRecord(ev[(size_t)2 * q], 0));
+      for (int c = 0; c < -m_list[q]; c++)
+        hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, 0, S, tiles, 1e-3);
+      BA_HIP_CHECK(hipEventRecord(ev[(size_t)2 * q + 1], 0));
+      continue;
+    }
+    const int m = m_list[q], nblk = m * (m + 1) / 2, grid = ((nblk + 7) / 8) * 8;
+    BA_HIP_CHECK(hipEventRecord(ev[(size_t)2 * q], 0));
+    hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0,
+                       nt - m, nt, nblk, (int *)nullptr);
+    BA_HIP_CHECK(hipEventRecord(ev[(size_t)2 * q + 1], 0));
+  }
+  BA_HIP_CHECK(hipDeviceSynchronize());
+  for (int q = 0; q < n; q++) {
+    float t = 0;
+    BA_HIP_CHECK(hipEventElapsedTime(&t, ev[(size_t)2 * q], ev[(size_t)2 * q + 1]));
+    ms_out[q] = t;
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
   (void)hipFree(S);
   (void)hipFree(V);
   (void)hipFree(co);
