@@ -62,7 +62,8 @@ constexpr size_t GEMM_LDS_ELEMS = (size_t)(DBUF ? 2 : 1) * 2 * NB * LDK;
 // upper triangle of the LDS image.  Writes L (scaled, D on the diagonal) back in place, Linv and D.
 constexpr int LDA2 = 130;  // row stride 260 dwords = 4 mod 64: conflict-free MFMA operand reads
 constexpr int XDL = 18;
-constexpr size_t DIAG_LDS_ELEMS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB + 16 * 17);
+constexpr int L16S = 18;   // row stride of the 16x16 multiplier block: 16-byte aligned rows for the row solves' paired reads
+constexpr size_t DIAG_LDS_ELEMS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB + 16 * L16S);
 
 // broadcast lane `src` (a compile-time constant after unrolling) of v to the whole wave: v_readlane_b32 into SGPRs
 template <typename T>
@@ -153,80 +154,116 @@ __device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T 
   for (int idx = tid; idx < 8 * 16 * XDL; idx += 256) xd[idx] = 0.0;
   __syncthreads();
   STAMP(0)
-  for (int jb = 0; jb < 8; jb++) {
+  // unblocked LDL' of the 16x16 diagonal block jb in the registers of one wave: lane i holds row i, a pivot and the
+  // pivot column travel by v_readlane (constant lane numbers after unrolling) -- no LDS round trip and no barrier
+  // inside the 16 dependent steps (the LDS version with a workgroup barrier per pivot took 3 us per block).
+  auto pivots = [&](int jb) {
     const int o = 16 * jb;
-    if (wv == 0) {
-      // unblocked LDL' of the 16x16 diagonal block in the registers of one wave: lane i holds row i, a pivot and the
-      // pivot column travel by v_readlane (constant lane numbers after unrolling) -- no LDS round trip and no barrier
-      // inside the 16 dependent steps (the LDS version with a workgroup barrier per pivot took 3 us per block).
-      const int i = lane & 15;  // lanes 16..63 shadow lanes 0..15
-      T r[16], invs[16];
+    const int i = lane & 15;  // lanes 16..63 shadow lanes 0..15
+    T r[16], invs[16];
 #pragma unroll
-      for (int c = 0; c < 16; c++) r[c] = a[(o + i) * LDA2 + o + c];
-      T myd = 0, myinv = 0;
+    for (int c = 0; c < 16; c++) r[c] = a[(o + i) * LDA2 + o + c];
+    T myd = 0, myinv = 0;
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const T d = bcast_lane<T>(r[j], j);
-        const T inv = fast_recip<T>(d);
-        invs[j] = inv;
-        if (i == j) {
-          myd = d;
-          myinv = inv;
-        }
-        const T t = r[j] * inv;
-#pragma unroll
-        for (int c = j + 1; c < 16; c++) r[c] -= t * bcast_lane<T>(r[j], c);  // rows above the diagonal carry garbage, unused
+    for (int j = 0; j < 16; j++) {
+      const T d = bcast_lane<T>(r[j], j);
+      const T inv = fast_recip<T>(d);
+      invs[j] = inv;
+      if (i == j) {
+        myd = d;
+        myinv = inv;
       }
-      if (lane < 16) {
+      const T t = r[j] * inv;
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-          if (c < i) a[(o + i) * LDA2 + o + c] = r[c];             // X = L D stays unscaled in the tile image
-          l16[i * 17 + c] = (c < i) ? r[c] * invs[c] : (T)0;      // scaled copy for the row solves below (broadcast reads)
+      for (int c = j + 1; c < 16; c++) r[c] -= t * bcast_lane<T>(r[j], c);  // rows above the diagonal carry garbage, unused
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < i) a[(o + i) * LDA2 + o + c] = r[c];               // X = L D stays unscaled in the tile image
+        l16[i * L16S + c] = (c < i) ? r[c] * invs[c] : (T)0;      // scaled copy for the row solves below (broadcast reads)
+      }
+      dd[o + i] = myd;
+      dinv[o + i] = myinv;
+      if (myd == (T)0) *flag = 1;
+    }
+  };
+  // X = A(:,jb) L16^-T for the rows below the diagonal block by forward substitution, one row per thread (the rows
+  // are independent; X = L D stays unscaled).
+  auto row_solves = [&](int jb) {
+    const int o = 16 * jb;
+    if (tid < NB - o - 16) {
+      const int r = o + 16 + tid;
+      // the 120 multipliers are the same for every row: all of them are requested up front (16-byte LDS reads, the
+      // same address in every lane), then the substitution runs column by column out of registers -- element c still
+      // receives its subtractions in the order m = 0, 1, ..., c-1 (3 340 -> 2 120 cycles per block column)
+      T l[16][16];
+#pragma unroll
+      for (int c = 1; c < 16; c++)
+#pragma unroll
+        for (int m = 0; m < c; m += 2) {
+          const d2 v = *reinterpret_cast<const d2 *>(l16 + c * L16S + m);
+          l[c][m] = v[0];
+          if (m + 1 < c) l[c][m + 1] = v[1];
         }
-        dd[o + i] = myd;
-        dinv[o + i] = myinv;
-        if (myd == (T)0) *flag = 1;
+      T xr[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) xr[c] = a[r * LDA2 + o + c];
+#pragma unroll
+      for (int m = 0; m < 15; m++)
+#pragma unroll
+        for (int c = m + 1; c < 16; c++) xr[c] -= xr[m] * l[c][m];
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[r * LDA2 + o + c] = xr[c];
+    }
+  };
+  // C(I,J) -= X(I) * (X(J) D^-1)' with the X of block column jb
+  auto block_update = [&](int jb, int I, int J) {
+    const int o = 16 * jb;
+    d4 acc;
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc[g] = a[(16 * I + RT<T>::row(lane, g)) * LDA2 + 16 * J + fr];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const int k = o + 4 * kk + fk;
+      acc = RT<T>::mfma(-a[(16 * I + fr) * LDA2 + k], a[(16 * J + fr) * LDA2 + k] * dinv[k], acc);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) a[(16 * I + RT<T>::row(lane, g)) * LDA2 + 16 * J + fr] = acc[g];
+  };
+  // Look-ahead of one block column: once block column jb+1 has received the update of block column jb, one wave factors
+  // its diagonal block while the other three apply update jb to the block columns right of it; only
+  // update(column jb+1) -> pivots(jb+1) -> row solves(jb+1) remains a dependent chain.  Every block still receives its
+  // updates in the order jb = 0, 1, ...: the arithmetic is that of the plain right-looking loop, bit for bit
+  // (tools/bench_diag.py prints a fingerprint of the outputs; 63.1 -> 58.1 us, with the row solves above 53.4 us).
+  // (Tried and dropped: one accumulator per k-slice in block_update and in the inverse below -- four independent MFMA
+  // chains instead of one dependent chain: slower, 60 us; the chain is not what these phases wait for.)
+  if (wv == 0) pivots(0);
+  __syncthreads();
+  STAMP(1)
+  row_solves(0);
+  __syncthreads();
+  STAMP(2)
+  for (int jb = 0; jb < 7; jb++) {
+    for (int I = jb + 1 + wv; I < 8; I += 4) block_update(jb, I, jb + 1);
+    __syncthreads();
+    STAMP(3)
+    if (wv == 0) {
+      pivots(jb + 1);
+    } else {  // blocks (I, J), jb + 2 <= J <= I < 8, dealt to waves 1..3
+      const int mb = 6 - jb, nblk = mb * (mb + 1) / 2;
+      for (int t = wv - 1; t < nblk; t += 3) {
+        int ii = 0;
+        while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+        const int jj = t - ii * (ii + 1) / 2;
+        block_update(jb, jb + 2 + ii, jb + 2 + jj);
       }
     }
     __syncthreads();
     STAMP(1)
-    // X = A(:,jb) L16^-T for the rows below the diagonal block by forward substitution, one row per thread (the rows
-    // are independent; X = L D stays unscaled).
-    if (tid < NB - o - 16) {
-      const int r = o + 16 + tid;
-      T xr[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        T sacc = a[r * LDA2 + o + c];
-#pragma unroll
-        for (int m = 0; m < c; m++) sacc -= xr[m] * l16[c * 17 + m];
-        xr[c] = sacc;
-      }
-#pragma unroll
-      for (int c = 0; c < 16; c++) a[r * LDA2 + o + c] = xr[c];
-    }
+    row_solves(jb + 1);
     __syncthreads();
     STAMP(2)
-    // C(I,J) -= X(I) * (X(J) D^-1)'
-    const int mb = 7 - jb, nblk = mb * (mb + 1) / 2;
-    for (int t = wv; t < nblk; t += 4) {
-      int ii = 0;
-      while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-      const int jj = t - ii * (ii + 1) / 2;
-      const int I = jb + 1 + ii, J = jb + 1 + jj;
-      d4 acc;
-#pragma unroll
-      for (int g = 0; g < 4; g++) acc[g] = a[(16 * I + RT<T>::row(lane, g)) * LDA2 + 16 * J + fr];
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int k = o + 4 * kk + fk;
-        acc = RT<T>::mfma(-a[(16 * I + fr) * LDA2 + k], a[(16 * J + fr) * LDA2 + k] * dinv[k], acc);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; g++) a[(16 * I + RT<T>::row(lane, g)) * LDA2 + 16 * J + fr] = acc[g];
-    }
-    __syncthreads();
-    STAMP(3)
   }
   if (tid < 128) {  // the eight 16x16 unit-lower inverses, one column per thread: l[i][m] = a[i][m] * dinv[m]
     const int o = 16 * (tid >> 4), c = tid & 15;

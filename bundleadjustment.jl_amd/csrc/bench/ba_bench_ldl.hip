@@ -179,6 +179,19 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
     BA_HIP_CHECK(hipEventSynchronize(e1));
     if (rep == 1) BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   }
+  {  // fingerprint of the outputs (inverse tile + pivots): refactorings of the kernel are expected to keep every bit
+    std::vector<double> li((size_t)NB * NB), dv(NB);
+    BA_HIP_CHECK(hipMemcpy(li.data(), Li, li.size() * sizeof(double), hipMemcpyDeviceToHost));
+    BA_HIP_CHECK(hipMemcpy(dv.data(), D, dv.size() * sizeof(double), hipMemcpyDeviceToHost));
+    unsigned long long hsh = 1469598103934665603ull;
+    auto mix = [&](const std::vector<double> &v) {
+      const unsigned char *b = reinterpret_cast<const unsigned char *>(v.data());
+      for (size_t q = 0; q < v.size() * sizeof(double); q++) hsh = (hsh ^ b[q]) * 1099511628211ull;
+    };
+    mix(li);
+    mix(dv);
+    fprintf(stderr, "[diag] output fingerprint %016llx  D[0] %.17g D[127] %.17g Linv[127][0] %.17g\n", hsh, dv[0], dv[127], li[(size_t)127 * NB]);
+  }
   unsigned long long hs[6];
   BA_HIP_CHECK(hipMemcpy(hs, st, sizeof hs, hipMemcpyDeviceToHost));
   for (int q = 0; q < 6; q++) cycles6[q] = (double)hs[q];
@@ -393,6 +406,51 @@ __global__ __launch_bounds__(256, 2) void k_dma_probe(const double *__restrict__
 }
 
 }  // namespace
+
+// The diagonal-tile kernel (one workgroup, a chain of dependent instructions) alone on the device against the same kernel
+// beside `fill_blocks` workgroups of pure MFMA work on another stream: is its time set by the clock the device grants an
+// almost idle chip?  us_out: n launches alone, then n launches started right behind the filler (tools/bench_diag_busy.py)
+extern "C" int ba_debug_diag_busy(int n, int fill_blocks, int fill_iters, double *us_out) {
+  BA_CHECK(set_bench_kernel_attrs());
+  double *S = nullptr, *Li = nullptr, *D = nullptr, *out = nullptr;
+  int *flag = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&S, NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&Li, NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMemset(Li, 0, NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&D, NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&flag, sizeof(int)));
+  BA_HIP_CHECK(hipMalloc((void **)&out, (size_t)(fill_blocks > 0 ? fill_blocks : 1) * 256 * sizeof(double)));
+  std::vector<double> h((size_t)NB * NB, 0.0);
+  for (int i = 0; i < NB; i++)
+    for (int j = 0; j <= i; j++) h[(size_t)i * NB + j] = (i == j) ? 300.0 + i : 1.0 / (1 + i + j);
+  BA_HIP_CHECK(hipMemcpy(S, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  hipStream_t sa, sb;
+  BA_HIP_CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+  BA_HIP_CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+  std::vector<hipEvent_t> ev((size_t)2 * n + 2);
+  for (auto &e : ev) BA_HIP_CHECK(hipEventCreate(&e));
+  for (int phase = 0; phase < 2; phase++) {
+    BA_HIP_CHECK(hipDeviceSynchronize());
+    if (phase == 1 && fill_blocks > 0)
+      hipLaunchKernelGGL(k_mfma_probe<0>, dim3(fill_blocks), dim3(256), 0, sb, out, fill_iters);
+    BA_HIP_CHECK(hipEventRecord(ev[0], sa));
+    for (int q = 0; q < n; q++) {  // (the kernel only reads S: every launch factors the same tile)
+      hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(double), sa, S, Li, D, flag,
+                         (unsigned long long *)nullptr, (const int *)nullptr);
+      BA_HIP_CHECK(hipEventRecord(ev[(size_t)q + 1], sa));
+    }
+    BA_HIP_CHECK(hipDeviceSynchronize());
+    for (int q = 0; q < n; q++) {
+      float t = 0;
+      BA_HIP_CHECK(hipEventElapsedTime(&t, ev[(size_t)q], ev[(size_t)q + 1]));
+      us_out[phase * n + q] = 1e3 * t;
+    }
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(sa); (void)hipStreamDestroy(sb);
+  (void)hipFree(S); (void)hipFree(Li); (void)hipFree(D); (void)hipFree(flag); (void)hipFree(out);
+  return BA_OK;
+}
 
 extern "C" int ba_debug_mfma_probe(int mode, int iters, double *tflops_out) {
   int dev = 0, ncu = 256;
