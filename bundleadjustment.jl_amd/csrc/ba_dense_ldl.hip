@@ -138,16 +138,16 @@ __device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T 
   T *a = sm, *xd = sm + NB * LDA2, *dd = xd + 8 * 16 * XDL, *dinv = dd + NB, *l16 = dinv + NB;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  // tile -> LDS: 16-byte loads, 8 in flight per thread (unpredicated: loads under a per-thread condition serialise).
+  // tile -> LDS: 16-byte loads, 16 in flight per thread (unpredicated: loads under a per-thread condition serialise).
   // The strict upper triangle of the LDS image is never read before the inverse phase writes it.
 #pragma unroll
-  for (int b0 = 0; b0 < 4; b0++) {
-    d2 v[8];
+  for (int b0 = 0; b0 < 2; b0++) {
+    d2 v[16];
 #pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const d2 *>(Skk + 2 * ((b0 * 8 + q) * 256 + tid));
+    for (int q = 0; q < 16; q++) v[q] = *reinterpret_cast<const d2 *>(Skk + 2 * ((b0 * 16 + q) * 256 + tid));
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int idx = 2 * ((b0 * 8 + q) * 256 + tid), i = idx >> 7, j = idx & (NB - 1);
+    for (int q = 0; q < 16; q++) {
+      const int idx = 2 * ((b0 * 16 + q) * 256 + tid), i = idx >> 7, j = idx & (NB - 1);
       *reinterpret_cast<d2 *>(a + i * LDA2 + j) = v[q];
     }
   }
@@ -312,6 +312,7 @@ __device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T 
   STAMP(4)
   // LDS -> Linv tile (lower triangle only: the upper triangle of the buffer is zeroed once, when it is allocated) and D.
   // The factored diagonal tile itself is not written back: nothing reads it (panel solves and sweeps use Linv and D).
+#pragma unroll 8
   for (int it = 0; it < 32; it++) {
     const int idx = 2 * (it * 256 + tid), i = idx >> 7, c0 = idx & (NB - 1);
     if (c0 > i) continue;
