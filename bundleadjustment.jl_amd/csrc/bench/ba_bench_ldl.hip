@@ -7,7 +7,16 @@
 namespace {
 __global__ void k_probe_fill(double *a, size_t n, double scale) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i] = scale * (double)((i * 2654435761u) % 1021) / 1021.0 - 0.3;
+  if (i >= n) return;
+  if (scale < 0) {  // full-entropy mantissas (splitmix64), values in (-|scale|, |scale|)
+    unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    a[i] = -scale * ((double)(long long)z / 9223372036854775808.0);
+  } else {
+    a[i] = scale * (double)((i * 2654435761u) % 1021) / 1021.0 - 0.3;
+  }
 }
 }  // namespace
 
@@ -109,8 +118,9 @@ extern "C" int ba_debug_update_seq(int nt, int n, const int *m_list, const int *
   double *S = nullptr, *V = nullptr;
   BA_HIP_CHECK(hipMalloc((void **)&S, tiles * sizeof(double)));
   BA_HIP_CHECK(hipMalloc((void **)&V, vel * sizeof(double)));
-  hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, 0, S, tiles, 1e-3);
-  hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((vel + 255) / 256)), dim3(256), 0, 0, V, vel, 1e-3);
+  const double fs = getenv("BA_BENCH_RANDOM") ? -1.0 : 1e-3;  // random mantissas (what a real matrix has) or 1021 distinct values
+  hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, 0, S, tiles, fs);
+  hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((vel + 255) / 256)), dim3(256), 0, 0, V, vel, fs);
   std::vector<int64_t> h_co;
   dense_ldl_layout(nt, 1, &h_co, nullptr);
   int64_t *co = nullptr;

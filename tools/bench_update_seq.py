@@ -53,3 +53,16 @@ show("20 ms idle, 40 fills, ramp, 16 big", [-40] + ramp + [big] * 16, [20000] + 
 show("20 ms idle, 16 big (third)", [big] * 16, [20000] + [0] * 15)
 show("20 ms idle, 4 x m=64, 16 big", [64] * 4 + [big] * 16, [20000] + [0] * 19)
 show("20 ms idle, 1 x m=32, 16 big", [32] + [big] * 16, [20000] + [0] * 16)
+
+# the LM loop in miniature: [memory-bound phase] + the 62 updates of one factorisation, five times in one stream
+fact = list(range(big, 1, -2))
+for fills in (35, 10, 0):
+    seq = ([-fills] if fills else []) + fact
+    m = np.asarray(seq * 5, dtype=np.int32)
+    out = run_raw(m, None)
+    per = out.reshape(5, len(seq))
+    upd = per[:, 1:] if fills else per
+    print(f"--- 5 x [{fills} fills + factorisation order]: update sums per factorisation (ms): " + " ".join(f"{v:.2f}" for v in upd.sum(1))
+          + (f"; fills {per[:, 0].mean():.2f} ms" if fills else ""))
+    t = np.asarray(fact[:8]); tl = t * (t + 1) // 2
+    print("    us/tile of the first 8 launches, last repetition: " + " ".join(f"{1e3 * v / n:.3f}" for v, n in zip(upd[-1, :8], tl)))
