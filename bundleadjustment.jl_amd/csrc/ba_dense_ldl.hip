@@ -6,7 +6,8 @@
 // src/ldl_aux.jl:199 -> BA_ERR_ZERO_PIVOT); S is symmetric positive definite in exact arithmetic.
 //
 // Storage: lower block triangle of NB x NB (128) tiles, each tile contiguous row-major (ba_internal.h).
-// Right-looking, one panel (tile column) per step k:
+// Right-looking, panels (tile columns) taken in pairs; the kernels of round 1's schedule (dense_ldl_factor has the fused
+// pair schedule of round 2, k_ldl_pairdiag / k_ldl_pairtrsm, and dense_ldl_factor_dist the distributed one):
 //   k_ldl_diag     : one workgroup factors tile (k,k) in LDS (L_kk, D_k) and forms L_kk^-1 explicitly;
 //   k_ldl_trsm_rs  : X_i = S_ik L_kk^-T (= L_ik D_k) as an MFMA product with L_kk^-1 (32 rows per workgroup), stores
 //                    V_i = X_i and L_ik = X_i D_k^-1; the forward substitution of the right-hand side rides along;
@@ -56,10 +57,12 @@ constexpr size_t GEMM_LDS_ELEMS = (size_t)(DBUF ? 2 : 1) * 2 * NB * LDK;
 
 // ---- diagonal tile ---------------------------------------------------------------------------------------------
 // One workgroup (4 waves) factors the 128x128 tile in LDS as 8x8 blocks of 16x16:
-//   for each block column jb: unblocked LDL' of the 16x16 diagonal block, its unit-lower inverse (16 lanes, registers),
-//   X(I) = A(I,jb) Linv16' by MFMA (kept unscaled: X = L D), trailing blocks C(I,J) -= X(I) (X(J) D^-1)' by MFMA;
-// then the full unit-lower inverse of the tile by block forward substitution (MFMA), stored transposed in the
-// upper triangle of the LDS image.  Writes L (scaled, D on the diagonal) back in place, Linv and D.
+//   for each block column jb: unblocked LDL' of the 16x16 diagonal block (one wave, registers), the rows below it by
+//   forward substitution, one row per thread (kept unscaled: X = L D), trailing blocks C(I,J) -= X(I) (X(J) D^-1)' by
+//   MFMA -- with a look-ahead of one block column (see diag_tile);
+// then the eight 16x16 unit-lower inverses and the full unit-lower inverse of the tile by block forward substitution
+// (MFMA), stored transposed in the upper triangle of the LDS image.  Writes the inverse's lower triangle and D; the
+// factored tile itself is not written back (nothing reads it).
 constexpr int LDA2 = 130;  // row stride 260 dwords = 4 mod 64: conflict-free MFMA operand reads
 constexpr int XDL = 18;
 constexpr int L16S = 18;   // row stride of the 16x16 multiplier block: 16-byte aligned rows for the row solves' paired reads
