@@ -90,7 +90,8 @@ int ba_jac_coord_f32(ba_problem *p, const float *x, float *vals);
  * called at src/lm.jl:57,370.  jtr has nvar entries in the layout of x. */
 int ba_jtr(ba_problem *p, const double *vals, const double *r, double *jtr);
 
-/* device-resident twins (no host copies, no synchronisation): what bench.py times */
+/* device-resident twins (no host copies, no synchronisation): what bench.py times.  The kernels move 16 bytes per
+ * lane: arrays aligned to 16 bytes (any hipMalloc / torch allocation is) run at the quoted rates. */
 int ba_residual_dev(ba_problem *p, const double *d_x, double *d_r, void *stream);
 int ba_residual_f32_dev(ba_problem *p, const float *d_x, float *d_r, void *stream);
 int ba_jac_structure_dev(ba_problem *p, int64_t *d_rows, int64_t *d_cols, void *stream);
