@@ -443,57 +443,71 @@ __device__ inline void tile_gemm_abt(const T *__restrict__ A0, const T *__restri
 
 // Wave-private variant: every wave stages the 64 A rows and 64 B rows IT needs in its own LDS region, so the K loop has
 // no workgroup barrier at all (each operand slice is loaded by the two waves that use it: 2x the L2->LDS traffic, which
-// is not the limiter).  LDS: 4 waves x 128 rows x 18 doubles = 73.7 KB.
-constexpr size_t GEMM_PRIV_LDS_ELEMS = (size_t)4 * 2 * 64 * LDK;
+// is not the limiter).  A chunk is 128 bytes of every row -- 16 doubles or 32 floats -- moved in 16-byte pieces, so both
+// types issue the same loads / LDS writes per chunk against the same 4096 cycles of MFMA work (with 16-float chunks moved
+// in 8-byte pieces the Float32 update ran at 57 % of its peak where the Float64 one reaches 70-75 %: the per-chunk
+// overhead is fixed, the Float32 matrix instructions are twice as fast).  LDS: 4 waves x 128 rows x 144 bytes = 73.7 KB;
+// row strides 18 doubles / 36 floats: 16-byte aligned, conflict-free operand reads.
+template <typename T>
+struct PV {
+  static constexpr int VL = 16 / sizeof(T);                  // elements per 16-byte piece
+  static constexpr int KC = 128 / sizeof(T);                 // chunk width
+  static constexpr int LDK = KC + (sizeof(T) == 8 ? 2 : 4);  // LDS row stride (elements)
+  typedef T vu __attribute__((ext_vector_type(16 / sizeof(T))));
+};
+template <typename T>
+constexpr size_t gemm_priv_lds_bytes() { return (size_t)4 * 2 * 64 * PV<T>::LDK * sizeof(T); }
+constexpr size_t GEMM_PRIV_LDS_ELEMS = gemm_priv_lds_bytes<double>() / sizeof(double);  // (Float64 micro-benchmarks)
 template <typename T, int NP>
 __device__ inline void tile_gemm_abt_priv(const T *__restrict__ A0, const T *__restrict__ B0,
                                           const T *__restrict__ A1, const T *__restrict__ B1, T *lds,
                                           typename RT<T>::v4 acc[4][4]) {
-  BA_VT
+  typedef typename PV<T>::vu vu;
+  constexpr int PKC = PV<T>::KC, PLDK = PV<T>::LDK, VL = PV<T>::VL;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
   const int fr = lane & 15, fk = lane >> 4;
-  T *sA = lds + wv * (2 * 64 * LDK), *sB = sA + 64 * LDK;
-  constexpr int UPR = KC / 2;       // 16-byte units per row of a chunk (8)
+  T *sA = lds + wv * (2 * 64 * PLDK), *sB = sA + 64 * PLDK;
+  constexpr int UPR = PKC / VL;     // 16-byte pieces per row of a chunk (8)
   constexpr int RPS = 64 / UPR;     // rows per step of the 64 lanes (8)
   constexpr int NLD = 64 / RPS;     // steps to cover 64 rows (8)
-  const int lrow = lane / UPR, lc2 = lane % UPR;
-  d2 pa[NLD], pb[NLD];
+  const int lrow = lane / UPR, lc = (lane % UPR) * VL;
+  vu pa[NLD], pb[NLD];
   const T *Ab = A0 + wr * NB, *Bb = B0 + wc * NB;
 #pragma unroll
   for (int it = 0; it < NLD; it++) {
-    pa[it] = *reinterpret_cast<const d2 *>(Ab + (lrow + RPS * it) * NB + 2 * lc2);
-    pb[it] = *reinterpret_cast<const d2 *>(Bb + (lrow + RPS * it) * NB + 2 * lc2);
+    pa[it] = *reinterpret_cast<const vu *>(Ab + (lrow + RPS * it) * NB + lc);
+    pb[it] = *reinterpret_cast<const vu *>(Bb + (lrow + RPS * it) * NB + lc);
   }
-  constexpr int NCH = NP * (NB / KC);
+  constexpr int NCH = NP * (NB / PKC);
   for (int ch = 0; ch < NCH; ch++) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int it = 0; it < NLD; it++) {
-      *reinterpret_cast<d2 *>(sA + (lrow + RPS * it) * LDK + 2 * lc2) = pa[it];
-      *reinterpret_cast<d2 *>(sB + (lrow + RPS * it) * LDK + 2 * lc2) = pb[it];
+      *reinterpret_cast<vu *>(sA + (lrow + RPS * it) * PLDK + lc) = pa[it];
+      *reinterpret_cast<vu *>(sB + (lrow + RPS * it) * PLDK + lc) = pb[it];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nx = ch + 1;
     if (nx < NCH) {
-      const T *A = ((NP == 2 && nx >= NB / KC) ? A1 : A0) + wr * NB;
-      const T *B = ((NP == 2 && nx >= NB / KC) ? B1 : B0) + wc * NB;
-      const int k0 = (nx & (NB / KC - 1)) * KC;
+      const T *A = ((NP == 2 && nx >= NB / PKC) ? A1 : A0) + wr * NB;
+      const T *B = ((NP == 2 && nx >= NB / PKC) ? B1 : B0) + wc * NB;
+      const int k0 = (nx & (NB / PKC - 1)) * PKC;
 #pragma unroll
       for (int it = 0; it < NLD; it++) {
-        pa[it] = *reinterpret_cast<const d2 *>(A + (lrow + RPS * it) * NB + k0 + 2 * lc2);
-        pb[it] = *reinterpret_cast<const d2 *>(B + (lrow + RPS * it) * NB + k0 + 2 * lc2);
+        pa[it] = *reinterpret_cast<const vu *>(A + (lrow + RPS * it) * NB + k0 + lc);
+        pb[it] = *reinterpret_cast<const vu *>(B + (lrow + RPS * it) * NB + k0 + lc);
       }
     }
 #pragma unroll
-    for (int kk = 0; kk < KC / 4; kk++) {
+    for (int kk = 0; kk < PKC / 4; kk++) {
       T af[4], bf[4];
 #pragma unroll
-      for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * LDK + kk * 4 + fk];
+      for (int m = 0; m < 4; m++) af[m] = sA[(16 * m + fr) * PLDK + kk * 4 + fk];
 #pragma unroll
-      for (int n = 0; n < 4; n++) bf[n] = sB[(16 * n + fr) * LDK + kk * 4 + fk];
+      for (int n = 0; n < 4; n++) bf[n] = sB[(16 * n + fr) * PLDK + kk * 4 + fk];
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -1238,7 +1252,7 @@ static int set_kernel_attrs() {
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_diag<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_priv_lds_bytes<T>()));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_pairdiag<T, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_pairdiag<T, false>),
@@ -1248,7 +1262,7 @@ static int set_kernel_attrs() {
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_pairtrsm<T, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PT_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 0, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_priv_lds_bytes<T>()));
   g_attr_done = true;
   return BA_OK;
 }
@@ -1389,7 +1403,7 @@ static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, const T 
   // (Cutting the tiles of a partly filled last round into 64 x 64 quadrants, one workgroup each, was tried and removed:
   // 34.1-34.3 ms against 33.9-34.1 at n = 16 002.  A partial round does not cost a full one -- the quadrant kernel took
   // 39 us on average, which is what the big kernel's own last round costs.)
-  hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st, w->S,
+  hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S,
                      w->col_off, V0, V1, k, base, nt, nblk, ready, (const int *)nullptr, (const int64_t *)nullptr, 0, 0,
                      ready_tiles);
   return BA_OK;
@@ -1514,7 +1528,7 @@ static int launch_pair_owned(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0,
   if (nblk64 <= 0) return BA_OK;
   const int nblk = (int)nblk64;
   ProfScope ps(p, PC_LDL_UPDATE, st);
-  hipLaunchKernelGGL((k_ldl_update<T, 1, 0, true>), dim3(((nblk + 7) / 8) * 8), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(T), st,
+  hipLaunchKernelGGL((k_ldl_update<T, 1, 0, true>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st,
                      w->S, w->col_off, V0, V1, k, w->h_own_cols[(size_t)m0], (int)w->nt, nblk, (int *)nullptr, w->own_cols, w->own_pref, m0, m1);
   return BA_OK;
 }
