@@ -44,7 +44,7 @@ class LMStats(C.Structure):
 LOG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                      C.c_double, C.c_int)
 COMM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
-COMM_ALLREDUCE_F64, COMM_REDUCE_F64, COMM_BCAST_BYTES = 0, 1, 2
+COMM_ALLREDUCE_F64, COMM_REDUCE_F64, COMM_BCAST_BYTES, COMM_REDUCE_F32 = 0, 1, 2, 3
 COMM_ID_BYTES = 128
 
 # every symbol include/ba_hip.h declares (tests check that the library exports all of them)

@@ -108,6 +108,17 @@ int comm_reduce(ba_problem *p, double *d_buf, int64_t count, int root, hipStream
   return BA_OK;
 }
 
+int comm_reduce_f32(ba_problem *p, float *d_buf, int64_t count, int root, hipStream_t st) {
+  BaComm *c = &p->comm;
+  if (!c->active() || count <= 0) return BA_OK;
+  ProfScope ps(p, PC_COMM, st);
+  c->calls++;
+  c->bytes += 4 * count;
+  if (c->hook) return hook_call(c, BA_COMM_REDUCE_F32, d_buf, count, root, st);
+  BA_NCCL_CHECK(g_rccl.Reduce(d_buf, d_buf, (size_t)count, ncclFloat32, ncclSum, root, (ncclComm_t)c->nccl, st));
+  return BA_OK;
+}
+
 int comm_bcast(ba_problem *p, void *d_buf, int64_t bytes, int root, hipStream_t st) {
   BaComm *c = &p->comm;
   if (!c->active() || bytes <= 0) return BA_OK;

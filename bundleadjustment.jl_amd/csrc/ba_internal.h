@@ -190,6 +190,7 @@ int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool
 // ---- transport (ba_comm.hip): all on stream st, in place, no-ops without a communicator --------------------
 int comm_allreduce(ba_problem *p, double *d_buf, int64_t count, hipStream_t st);
 int comm_reduce(ba_problem *p, double *d_buf, int64_t count, int root, hipStream_t st);  // sum lands on root only
+int comm_reduce_f32(ba_problem *p, float *d_buf, int64_t count, int root, hipStream_t st);
 int comm_bcast(ba_problem *p, void *d_buf, int64_t bytes, int root, hipStream_t st);
 int comm_group_begin(ba_problem *p);  // RCCL: fuse the calls up to comm_group_end into one launch
 int comm_group_end(ba_problem *p);

@@ -329,14 +329,20 @@ static bool dist_factor_on(ba_problem *p) {
 
 // the partial sums of S held by every rank -> the complete tile columns on their owners (distributed factorisation), or
 // the complete S everywhere (replicated); the right-hand side is needed by every rank either way
-static int reduce_camera_system(ba_problem *p, LMWorkFull *w, hipStream_t st) {
+// s32: the factorisation will run in Float32 and nothing needs the Float64 sum (no column scaling): every rank rounds its
+// partial sums to Float32 first and the owners receive Float32 sums -- half the bytes of the largest transfer of the
+// iteration (Final-13682: 30 GB instead of 60); the sum of `world` rounded partials differs from the rounded sum by a few
+// Float32 ulps, the level of the factorisation itself.
+static int reduce_camera_system(ba_problem *p, LMWorkFull *w, hipStream_t st, bool s32 = false) {
   if (!p->comm.active()) return BA_OK;
   if (!dist_factor_on(p)) return comm_sum(p, w, 0, w->s.off_gc, st);  // S tiles and rhs are adjacent
+  if (s32) BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, dense_ldl_tiles_doubles(w->n), st));
   BA_CHECK(comm_group_begin(p));
   int rc = BA_OK;
   for (int r = 0; r < w->ldl.world && rc == BA_OK; r++) {
     const int64_t b = w->ldl.own_range[(size_t)r], e = w->ldl.own_range[(size_t)r + 1];
-    rc = comm_reduce(p, w->ldl.S + b * NB * NB, (e - b) * NB * NB, r, st);
+    rc = s32 ? comm_reduce_f32(p, w->ldl32.S + b * NB * NB, (e - b) * NB * NB, r, st)
+             : comm_reduce(p, w->ldl.S + b * NB * NB, (e - b) * NB * NB, r, st);
   }
   BA_CHECK(comm_group_end(p));
   BA_CHECK(rc);
@@ -406,8 +412,10 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
                                p->rank == 0 ? w->npad : w->n, st, d_lambda, damp));
   BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
   BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st));
-  BA_CHECK(reduce_camera_system(p, w, st));
   const bool dist = dist_factor_on(p);
+  const bool reduce32 = dist && facto_f32 && normalize == 0;
+  if (reduce32) BA_CHECK(ensure_f32(w));
+  BA_CHECK(reduce_camera_system(p, w, st, reduce32));
   if (normalize != 0) {  // :J / :A column scaling of the camera system from the GLOBAL diagonal (refresh_linearisation)
     BA_CHECK(launch_cam_scale(p, w->hdiag, normalize == 2 ? lambda : 0.0, w->colscale, st, d_lambda));
     BA_CHECK(launch_scale_S(p, w->n, w->ldl.nt, w->colscale, w->ldl.S, w->ldl.col_off, st));
@@ -416,7 +424,7 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   w->last_f32 = facto_f32;
   if (facto_f32) {  // round the assembled system to Float32, factor and solve there, widen the solution
     BA_CHECK(ensure_f32(w));
-    BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, dense_ldl_tiles_doubles(w->n), st));
+    if (!reduce32) BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, dense_ldl_tiles_doubles(w->n), st));
     BA_CHECK(launch_convert(w->rhs, w->rhs32, w->npad, st));
     if (dist) {
       BA_CHECK(dense_ldl_factor_dist<float>(p, &w->ldl32, st));

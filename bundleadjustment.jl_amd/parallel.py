@@ -101,14 +101,15 @@ class CameraBlockReducer:
 
         def _hook(ctx, op, d_buf, count, root, stream):
             try:
-                nbytes = count if op == _lib.COMM_BCAST_BYTES else 8 * count
+                esize, view = {_lib.COMM_BCAST_BYTES: (1, np.uint8), _lib.COMM_REDUCE_F32: (4, np.float32)}.get(op, (8, np.float64))
+                nbytes = esize * count
                 host = np.empty(nbytes, dtype=np.uint8)
                 _lib.check(L.ba_memcpy_d2h(h, _lib.ptr(host), C.c_void_p(d_buf), nbytes))  # drains the handle's stream first
-                t = torch.from_numpy(host if op == _lib.COMM_BCAST_BYTES else host.view(np.float64))
+                t = torch.from_numpy(host.view(view))
                 src = (lambda r: dist.get_global_rank(group, r) if group is not None else r)
                 if op == _lib.COMM_ALLREDUCE_F64:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                elif op == _lib.COMM_REDUCE_F64:
+                elif op in (_lib.COMM_REDUCE_F64, _lib.COMM_REDUCE_F32):
                     dist.reduce(t, dst=src(root), op=dist.ReduceOp.SUM, group=group)
                     if self.rank != root:
                         return 0  # only the root's buffer receives the sum

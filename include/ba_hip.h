@@ -169,10 +169,11 @@ int ba_lm_solve(ba_problem *p, const ba_lm_opts *opts, double *x_inout, ba_lm_st
  *                         128-byte id with ba_comm_get_unique_id and hands it to the other ranks by any means the host
  *                         has (torch.distributed, MPI.jl, a file); the call is collective (ncclCommInitRank).
  *   ba_lm_set_comm_hook : the host carries the data.  op: BA_COMM_ALLREDUCE_F64 (count doubles, sum, in place),
- *                         BA_COMM_REDUCE_F64 (count doubles, the sum lands on `root` only, in place),
+ *                         BA_COMM_REDUCE_F64 / BA_COMM_REDUCE_F32 (count doubles / floats, the sum lands on `root` only,
+ *                         in place; the Float32 form carries the reduced camera matrix of facto_type = Float32 runs),
  *                         BA_COMM_BCAST_BYTES (count bytes from `root`).  d_buf is a device pointer; the operation must
  *                         be ordered after prior work on `stream` and complete (or stream-ordered) on return. */
-enum { BA_COMM_ALLREDUCE_F64 = 0, BA_COMM_REDUCE_F64 = 1, BA_COMM_BCAST_BYTES = 2 };
+enum { BA_COMM_ALLREDUCE_F64 = 0, BA_COMM_REDUCE_F64 = 1, BA_COMM_BCAST_BYTES = 2, BA_COMM_REDUCE_F32 = 3 };
 #define BA_COMM_ID_BYTES 128
 typedef int (*ba_comm_fn)(void *ctx, int op, void *d_buf, int64_t count, int root, void *stream);
 int ba_comm_get_unique_id(void *id_out /* BA_COMM_ID_BYTES */);

@@ -127,6 +127,7 @@ def test_rccl_single_rank(ba, small_prob, gpu_ok):
     big = ba.synthetic.make_problem(70, 500, 2400, seed=8)
     bref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(big))
     d_ref, half_ref, _ = ba.lm_step(bref, big["x0"], 25.0)
+    d32_ref, _, _ = ba.lm_step(bref, big["x0"], 25.0, facto_type=np.float32)
     bref.close()
     wide = ba.synthetic.make_problem(200, 1500, 9000, seed=11)  # 15 tile rows: 8 pairs through the look-ahead's buffers
     wref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(wide))
@@ -150,6 +151,9 @@ def test_rccl_single_rank(ba, small_prob, gpu_ok):
         ba.parallel.CameraBlockReducer(bm)
         d, half, _ = ba.lm_step(bm, big["x0"], 25.0)
         assert np.linalg.norm(d - d_ref) <= 1e-10 * np.linalg.norm(d_ref) and abs(half - half_ref) <= 1e-11 * half_ref
+        # facto_type = Float32: the partial sums of the reduced camera matrix travel as Float32 (ncclFloat32 reduce)
+        d32, _, _ = ba.lm_step(bm, big["x0"], 25.0, facto_type=np.float32)
+        assert np.linalg.norm(d32 - d32_ref) <= 1e-4 * np.linalg.norm(d32_ref)
         bm.close()
         wm = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(wide))
         ba.parallel.CameraBlockReducer(wm)
