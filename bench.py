@@ -59,6 +59,10 @@ def parse():
                          "same shape (N = 1 only; 'none' skips it)")
     ap.add_argument("--facto-type", choices=["f64", "f32"], default="f64",
                     help="facto_type of lm.jl (f32 = the diffprecsions.jl path, BASELINE config 5); the default line is f64")
+    ap.add_argument("--facto", choices=["ldl", "pcg"], default="ldl",
+                    help="ldl: the reference's direct branch (the default line); pcg: the matrix-free CG extension "
+                         "(--pcg-tol: its relative residual)")
+    ap.add_argument("--pcg-tol", type=float, default=1e-8)
     ap.add_argument("--backend", default=os.environ.get("BA_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend: nccl (= RCCL, default) or gloo (host-staged all-reduce; rehearsal only)")
     ap.add_argument("--single-device", action="store_true",
@@ -67,12 +71,13 @@ def parse():
 
 
 FACTO_TYPE = None  # set from --facto-type
+FACTO, PCG_TOL = "LDL", None  # set from --facto / --pcg-tol
 
 
 def lm_fixed_iterations(ba, fr, k, x=None):
     """exactly k iterations of lm.jl: every stopping test disabled except the iteration cap"""
-    return ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False, x=x, ite_max=k - 1, restol=0.0, satol=0.0, srtol=0.0,
-                                  oatol=0.0, ortol=0.0, atol=0.0, rtol=0.0, log=False, facto_type=FACTO_TYPE)
+    return ba.Levenberg_Marquardt(fr, FACTO, "AMD", "None", False, x=x, ite_max=k - 1, restol=0.0, satol=0.0, srtol=0.0,
+                                  oatol=0.0, ortol=0.0, atol=0.0, rtol=0.0, log=False, facto_type=FACTO_TYPE, pcg_tol=PCG_TOL)
 
 
 def spawn_ranks(args):
@@ -91,8 +96,10 @@ def spawn_ranks(args):
 
 
 def main():
-    global FACTO_TYPE
+    global FACTO_TYPE, FACTO, PCG_TOL
     args = parse()
+    if args.facto == "pcg":
+        FACTO, PCG_TOL = "PCG", args.pcg_tol
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     if args.facto_type == "f32":
@@ -316,7 +323,7 @@ def main():
             "dtype": "f64" if args.facto_type == "f64" else "f64 (reduced camera system factored in f32)",
             "data": "synthetic",
             "config": {"workload": f"{args.workload} shape: ncams={ncams} npnts={npnts_g} nobs={nobs_g}, seed "
-                                   f"{ba.synthetic.BASE_SEED}, lm.jl variant, LDL/None, facto_type {args.facto_type}, fixed {args.steps} iterations"
+                                   f"{ba.synthetic.BASE_SEED}, lm.jl variant, {FACTO}/None" + (f" (pcg_tol {PCG_TOL:g})" if FACTO == "PCG" else "") + f", facto_type {args.facto_type}, fixed {args.steps} iterations"
                                    + ("" if args.scale == 1.0 else f" SCALED x{args.scale} (debug)"),
                        "parallelism": f"points sharded over {world} rank(s), cameras replicated"
                                       + ("" if world == 1 else "; reduced camera matrix reduced onto the owners of its tile column "
@@ -324,7 +331,7 @@ def main():
             "jacobian_mnnz_per_s": jac_mnnz,
             "jacobian_ms": jac_ms,
             "lm": {"accepted": st.n_accepted, "rejected": st.n_rejected, "objective": st.objective,
-                   "n_jacobian": st.n_jacobian, "n_factor": st.n_factor, "loop_s": st.loop_time},
+                   "n_jacobian": st.n_jacobian, "n_factor": st.n_factor, "n_cg": st.n_cg, "loop_s": st.loop_time},
             "roofline": roof,
             "roofline_jacobian": roof_jac,
             "roofline_residual": roof_res,

@@ -31,12 +31,12 @@ class LMOpts(C.Structure):
                 ("restol", C.c_double), ("satol", C.c_double), ("srtol", C.c_double), ("oatol", C.c_double),
                 ("ortol", C.c_double), ("atol", C.c_double), ("rtol", C.c_double),
                 ("nu_d", C.c_double), ("nu_m", C.c_double), ("lam", C.c_double), ("delta_d", C.c_double),
-                ("max_time", C.c_double)]
+                ("max_time", C.c_double), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int), ("reserved1", C.c_int)]
 
 
 class LMStats(C.Structure):
     _fields_ = [("status", C.c_int), ("iter", C.c_int), ("n_accepted", C.c_int), ("n_rejected", C.c_int),
-                ("n_residual", C.c_int), ("n_jacobian", C.c_int), ("n_factor", C.c_int), ("reserved0", C.c_int),
+                ("n_residual", C.c_int), ("n_jacobian", C.c_int), ("n_factor", C.c_int), ("n_cg", C.c_int),
                 ("objective", C.c_double), ("dual_feas", C.c_double), ("lambda_final", C.c_double),
                 ("elapsed_s", C.c_double), ("loop_s", C.c_double)]
 
@@ -55,7 +55,7 @@ SYMBOLS = [
     "ba_jac_structure_dev", "ba_jac_coord_dev", "ba_jac_coord_f32_dev", "ba_jtr_dev", "ba_dev_malloc", "ba_dev_free",
     "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_synchronize", "ba_lm_solve", "ba_comm_get_unique_id", "ba_lm_set_comm_rccl",
     "ba_lm_set_comm_hook", "ba_comm_stats", "ba_dist_layout",
-    "ba_lm_step", "ba_lm_step_f32", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
+    "ba_lm_step", "ba_lm_step_f32", "ba_lm_step_pcg", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
 ]
 
 _lib = None
@@ -100,6 +100,7 @@ def lib():
     L.ba_dist_layout.argtypes = [i64, C.c_int, vp, vp]
     L.ba_lm_step.argtypes = [vp, vp, f64, vp, C.POINTER(f64), vp]
     L.ba_lm_step_f32.argtypes = [vp, vp, f64, vp, C.POINTER(f64), vp]
+    L.ba_lm_step_pcg.argtypes = [vp, vp, f64, f64, C.c_int, vp, C.POINTER(f64), vp, C.POINTER(C.c_int)]
     L.ba_profile_enable.argtypes = [vp, C.c_int]
     L.ba_profile_reset.argtypes = [vp]
     L.ba_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(f64), C.POINTER(i64), C.POINTER(C.c_int)]

@@ -198,6 +198,15 @@ struct LMWorkFull : LMWork {
   int g_key = -1;  // normalize + 4 * facto_f32 + 8 * x_f32 the graphs were recorded for
   int parity = 0;
   bool g_off = false;  // a recording failed on this handle: plain launches from then on
+  // facto = PCG: block-Jacobi preconditioned conjugate gradients on the reduced camera system, S never formed (pcg_solve).
+  // Buffers allocated on first use: iterate, residual, preconditioned residual, direction, S * direction, W U^-1 W' part
+  // (n each), point-side intermediate and a zero vector (3 npnts), the 9 x 9 diagonal blocks (45 per camera).
+  bool pcg = false;
+  double pcg_tol = 1e-8;
+  int pcg_maxit = 0;  // 0: default
+  int64_t n_cg = 0;   // CG iterations of the current solve
+  double *cgx = nullptr, *cgr = nullptr, *cgz = nullptr, *cgp = nullptr, *cgq = nullptr, *cgt = nullptr;
+  double *cgh = nullptr, *zero3 = nullptr, *blk45 = nullptr, *cg_scal = nullptr, *h_cg = nullptr;
 };
 
 namespace {
@@ -306,6 +315,9 @@ void lm_free(ba_problem *p) {
     if (w->g_step[q]) (void)hipGraphExecDestroy(w->g_step[q]);
     if (w->g_refresh[q]) (void)hipGraphExecDestroy(w->g_refresh[q]);
   }
+  for (double *q : {w->cgx, w->cgr, w->cgz, w->cgp, w->cgq, w->cgt, w->cgh, w->zero3, w->blk45, w->cg_scal})
+    if (q) (void)hipFree(q);
+  if (w->h_cg) (void)hipHostFree(w->h_cg);
   if (w->d_lambda) (void)hipFree(w->d_lambda);
   if (w->h_lambda) (void)hipHostFree(w->h_lambda);
   if (w->h_flag) (void)hipHostFree(w->h_flag);
@@ -388,6 +400,86 @@ static int fetch_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st) {
   return BA_OK;
 }
 
+// ---- facto = PCG ------------------------------------------------------------------------------------------------------
+// The reference has no iterative branch (its solves are sparse direct, src/lm.jl:61-112); SURVEY 8(f) lists PCG on the
+// reduced camera system as the way to Final-scale problems, where the dense S (60 GB for Final-13682) and its n^3/3 flops
+// stop paying.  Here S = Hcc + lambda I - W U^-1 W' is applied, never formed: two sweeps over J per product (the
+// back-substitution pass by point, the right-hand-side pass by camera), preconditioned by its 9 x 9 diagonal blocks.  On
+// several ranks the product is summed by ONE all-reduce of 9 ncams doubles per CG iteration; everything else is replicated.
+static int ensure_pcg(ba_problem *p, LMWorkFull *w) {
+  if (w->cgx) return BA_OK;
+  auto dm = [](double **q, int64_t cnt) -> int {
+    BA_HIP_CHECK(hipMalloc((void **)q, (size_t)(cnt > 0 ? cnt : 1) * sizeof(double)));
+    BA_HIP_CHECK(hipMemset(*q, 0, (size_t)(cnt > 0 ? cnt : 1) * sizeof(double)));
+    return BA_OK;
+  };
+  for (double **q : {&w->cgx, &w->cgr, &w->cgz, &w->cgp, &w->cgq, &w->cgt}) BA_CHECK(dm(q, w->npad));
+  BA_CHECK(dm(&w->cgh, 3 * p->npnts));
+  BA_CHECK(dm(&w->zero3, 3 * p->npnts));
+  BA_CHECK(dm(&w->blk45, 45 * p->ncams));
+  BA_CHECK(dm(&w->cg_scal, 4));
+  BA_HIP_CHECK(hipHostMalloc((void **)&w->h_cg, 4 * sizeof(double)));
+  return BA_OK;
+}
+
+// q = S v (partial sums reduced over the ranks, then the damping, which every rank adds to the full sum)
+static int pcg_matvec(ba_problem *p, LMWorkFull *w, double lambda, const double *v, double *q, hipStream_t st) {
+  BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->zero3, v, w->cgh, st));  // h = -U^-1 W' v
+  BA_CHECK(launch_wuw(p, w->J, w->cgh, w->cgt, st));                      // t = W h = -W U^-1 W' v
+  BA_CHECK(launch_hcc_mv(p, w->Hcc, v, w->cgt, q, st));                   // Hcc v + t
+  BA_CHECK(comm_allreduce(p, q, w->n, st));
+  return launch_axpy_s(p, w->n, lambda, v, q, st);
+}
+
+static int pcg_fetch(LMWorkFull *w, hipStream_t st) {
+  BA_HIP_CHECK(hipMemcpyAsync(w->h_cg, w->cg_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+  BA_HIP_CHECK(hipStreamSynchronize(st));
+  return BA_OK;
+}
+
+// S x = rhs (w->rhs in, solution out) to |r| <= pcg_tol |rhs| or pcg_maxit iterations
+static int pcg_solve(ba_problem *p, LMWorkFull *w, double lambda, hipStream_t st) {
+  BA_CHECK(ensure_pcg(p, w));
+  const int64_t n = w->n;
+  const int maxit = w->pcg_maxit > 0 ? w->pcg_maxit : 1000;
+  BA_HIP_CHECK(hipMemsetAsync(w->ldl.flag, 0, sizeof(int), st));
+  BA_CHECK(launch_schur_diag(p, w->J, w->Uinv, w->Hcc, w->blk45, st));
+  BA_CHECK(comm_allreduce(p, w->blk45, 45 * p->ncams, st));
+  BA_CHECK(launch_pcg_factor(p, lambda, w->blk45, w->ldl.flag, st));  // a block that is not positive definite -> SQDException
+  BA_HIP_CHECK(hipMemsetAsync(w->cgx, 0, (size_t)n * sizeof(double), st));
+  BA_HIP_CHECK(hipMemcpyAsync(w->cgr, w->rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BA_CHECK(launch_pcg_apply(p, w->blk45, w->cgr, w->cgz, st));
+  BA_HIP_CHECK(hipMemcpyAsync(w->cgp, w->cgz, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BA_CHECK(launch_dot(p, n, w->cgr, w->cgz, w->partial, w->cg_scal, 2, st));
+  BA_CHECK(launch_dot(p, n, w->cgr, w->cgr, w->partial, w->cg_scal, 1, st));
+  BA_CHECK(pcg_fetch(w, st));
+  double rz = w->h_cg[2];
+  const double b2 = w->h_cg[1];
+  int it = 0;
+  if (b2 > 0 && rz == rz) {
+    for (it = 1; it <= maxit; it++) {
+      BA_CHECK(pcg_matvec(p, w, lambda, w->cgp, w->cgq, st));
+      BA_CHECK(launch_dot(p, n, w->cgp, w->cgq, w->partial, w->cg_scal, 0, st));
+      BA_CHECK(pcg_fetch(w, st));
+      const double pq = w->h_cg[0];
+      if (!(pq > 0)) break;  // S not positive definite along p (or NaN): keep what there is, the LM test judges the step
+      const double alpha = rz / pq;
+      BA_CHECK(launch_cg_update(p, n, alpha, w->cgp, w->cgq, w->cgx, w->cgr, st));
+      BA_CHECK(launch_pcg_apply(p, w->blk45, w->cgr, w->cgz, st));
+      BA_CHECK(launch_dot(p, n, w->cgr, w->cgr, w->partial, w->cg_scal, 1, st));
+      BA_CHECK(launch_dot(p, n, w->cgr, w->cgz, w->partial, w->cg_scal, 2, st));
+      BA_CHECK(pcg_fetch(w, st));
+      const double rr = w->h_cg[1], rz_new = w->h_cg[2];
+      if (!(rr == rr) || rr <= w->pcg_tol * w->pcg_tol * b2) break;
+      BA_CHECK(launch_cg_dir(p, n, rz_new / rz, w->cgz, w->cgp, st));
+      rz = rz_new;
+    }
+  }
+  w->n_cg += it < maxit ? it : maxit;
+  BA_HIP_CHECK(hipMemcpyAsync(w->rhs, w->cgx, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  return BA_OK;
+}
+
 // delta = -(J'J + lambda I)^-1 J'r at the current linearisation; also |J delta + r|^2 -> SH_MODEL, |delta|^2
 static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, hipStream_t st,
                        bool facto_f32 = false, const double *d_lambda = nullptr) {
@@ -408,6 +500,16 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
     normalize = 0;  // lm.jl:156,232: no column scaling of J in the Float16 branch
   }
   BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, d_lambda, damp));
+  if (w->pcg) {  // the reduced camera system is applied, not formed (pcg_solve); no column scaling: block Jacobi has its own
+    BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
+    BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st));
+    BA_CHECK(comm_sum(p, w, w->s.off_rhs, w->npad, st));
+    w->last_f32 = false;
+    BA_CHECK(pcg_solve(p, w, lambda, st));
+    double *dcp = w->delta + 3 * p->npnts;
+    BA_HIP_CHECK(hipMemcpyAsync(dcp, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return launch_backsub(p, Jl, w->Uinv, w->u, dcp, w->delta, st, rl, w->cr0(), w->partial, w->scal, SH_MODEL, &w->model_done);
+  }
   BA_CHECK(launch_schur_blocks(p, &w->tasks, Jl, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
                                p->rank == 0 ? w->npad : w->n, st, d_lambda, damp));
   BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
@@ -493,7 +595,7 @@ static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
 
 // ---- recorded launch sequences ------------------------------------------------------------------------------------------
 static bool graphs_allowed(ba_problem *p, LMWorkFull *w) {
-  if (w->g_off || p->prof_on || p->comm.active() || w->f16) return false;  // per-kernel events / communicator / Float16 path
+  if (w->g_off || p->prof_on || p->comm.active() || w->f16 || w->pcg) return false;  // per-kernel events / communicator / Float16 path
   // the hoisted-diagonal schedule of large factorisations has a kernel wait for a flag raised by a kernel running
   // beside it: only with real streams is that concurrency certain (and the graphs gain nothing at that size)
   if (w->ldl.nt >= 34) return false;  // = HOIST_MIN_TILES + 2 of dense_ldl_factor (above its HOIST_MAX_TILES graphs gain nothing either)
@@ -603,7 +705,7 @@ static int accept_refresh(ba_problem *p, LMWorkFull *w, bool xf32, hipStream_t s
 }
 
 static int lm_step_impl(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
-                        double *jtr, bool facto_f32) {
+                        double *jtr, bool facto_f32, bool pcg = false, double tol = 0, int max_iter = 0, int *cg_iters = nullptr) {
   if (!p || !x || !delta) {
     ba_set_error("ba_lm_step: null argument");
     return BA_ERR_ARG;
@@ -612,6 +714,10 @@ static int lm_step_impl(ba_problem *p, const double *x, double lambda, double *d
   BA_CHECK(lm_ensure(p));
   LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
   hipStream_t st = p->stream;
+  w->pcg = pcg;
+  w->pcg_tol = tol > 0 ? tol : 1e-8;
+  w->pcg_maxit = max_iter > 0 ? max_iter : 0;
+  w->n_cg = 0;
   BA_HIP_CHECK(hipMemcpyAsync(w->x, x, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
   w->f16 = false;
   BA_CHECK(refresh_linearisation(p, w, true, st));
@@ -632,7 +738,14 @@ static int lm_step_impl(ba_problem *p, const double *x, double lambda, double *d
   }
   BA_HIP_CHECK(hipStreamSynchronize(st));
   if (half_sq_model) *half_sq_model = 0.5 * w->s.h_sh[SH_MODEL];
+  if (cg_iters) *cg_iters = (int)w->n_cg;
+  w->pcg = false;
   return BA_OK;
+}
+
+extern "C" int ba_lm_step_pcg(ba_problem *p, const double *x, double lambda, double tol, int max_iter, double *delta,
+                              double *half_sq_model, double *jtr, int *cg_iters_out) {
+  return lm_step_impl(p, x, lambda, delta, half_sq_model, jtr, false, true, tol, max_iter, cg_iters_out);
 }
 
 extern "C" int ba_lm_step(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
@@ -655,8 +768,12 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     ba_set_error("ba_lm_solve: variant must be 0 (LevenbergMarquardt.jl) or 1 (lm.jl)");
     return BA_ERR_ARG;
   }
-  if (o->facto != 0 && o->facto != 1) {
-    ba_set_error("ba_lm_solve: facto must be 0 (:LDL) or 1 (:QR)");
+  if (o->facto < 0 || o->facto > 2) {
+    ba_set_error("ba_lm_solve: facto must be 0 (:LDL), 1 (:QR) or 2 (:PCG)");
+    return BA_ERR_ARG;
+  }
+  if (o->facto == 2 && o->facto_type == 2) {
+    ba_set_error("ba_lm_solve: facto = :PCG runs in Float64 (facto_type = Float16 belongs to the :LDL branch)");
     return BA_ERR_ARG;
   }
   if (o->facto_type < 0 || o->facto_type > 2) {
@@ -682,7 +799,11 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   if (xf32) BA_CHECK(ensure_xf32(p, w));
   w->f16 = V && o->facto_type == 2;
   if (w->f16) BA_CHECK(ensure_f16(p, w));
-  const bool facto_f32 = V && o->facto_type >= 1;  // Float16 inputs are eliminated and factored in Float32
+  const bool facto_f32 = V && o->facto_type >= 1 && o->facto != 2;  // Float16 inputs are eliminated and factored in Float32
+  w->pcg = o->facto == 2;
+  w->pcg_tol = o->pcg_tol > 0 ? o->pcg_tol : 1e-8;
+  w->pcg_maxit = o->pcg_max_iter > 0 ? o->pcg_max_iter : 0;
+  w->n_cg = 0;
   const double eps = xf32 ? 1.1920928955078125e-07 : 2.220446049250313e-16, sq = std::sqrt(eps), cbr = std::pow(eps, 1.0 / 3.0);
   const double restol = o->restol >= 0 ? o->restol : (V ? cbr : 100 * sq);
   const double satol = o->satol >= 0 ? o->satol : sq, srtol = o->srtol >= 0 ? o->srtol : sq;
@@ -693,7 +814,8 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   const double delta_d = o->delta_d > 0 ? o->delta_d : 2;
   const int ite_max = o->ite_max >= 0 ? o->ite_max : (V ? 200 : 100);
   const bool linesearch = V && o->linesearch;
-  const bool facto_qr = o->facto == 1;  // same device solve; the branches differ in the line search's model value only
+  const bool facto_qr = o->facto >= 1;  // same device solve; the branches differ in the line search's model value only
+                                        // (:PCG has no dr vector to recur on either: it re-evaluates like :QR)
 
   memset(stats, 0, sizeof *stats);
   stats->status = BA_ST_UNKNOWN;
@@ -850,6 +972,8 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   stats->objective = obj;
   stats->dual_feas = norm_Jtr;
   stats->lambda_final = lambda;
+  stats->n_cg = (int)w->n_cg;
+  w->pcg = false;
   {
     hipError_t e = hipMemcpyAsync(x_inout, w->x, (size_t)w->nvar * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

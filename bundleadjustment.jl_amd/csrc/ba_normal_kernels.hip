@@ -61,7 +61,7 @@ __global__ __launch_bounds__(BLK) void k_point_blocks(int64_t npnts, const int *
 
 // ---- camera side: one workgroup per camera, fixed-order tree ----------------------------------------------
 // MODE 0: Hcc (45, packed lower row-major) and gc = B' r (9).   MODE 1: gc only.
-// MODE 2: rhs = sum_a B_a' (A_a u_p(a) - r_a)   (u = U^-1 gp per point).
+// MODE 2: rhs = sum_a B_a' (A_a u_p(a) - r_a)   (u = U^-1 gp per point).   MODE 3: sum_a B_a' A_a u_p(a) (PCG matvec).
 template <int MODE>
 __global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_ptr, const int *__restrict__ cam_obs,
                                                      const int *__restrict__ pnt0, const double *__restrict__ J,
@@ -87,6 +87,10 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_
       const double *up = u + 3 * (int64_t)pnt0[o];
       w0 = (Jo[0] * up[0] + Jo[1] * up[1] + Jo[2] * up[2]) - r[2 * o];
       w1 = (Jo[12] * up[0] + Jo[13] * up[1] + Jo[14] * up[2]) - r[2 * o + 1];
+    } else if (MODE == 3) {
+      const double *up = u + 3 * (int64_t)pnt0[o];
+      w0 = Jo[0] * up[0] + Jo[1] * up[1] + Jo[2] * up[2];
+      w1 = Jo[12] * up[0] + Jo[13] * up[1] + Jo[14] * up[2];
     } else {
       w0 = r[2 * o];
       w1 = r[2 * o + 1];
@@ -198,6 +202,10 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ c
         const double *up = u + 3 * (int64_t)pnt0[o];
         w0 = (Jo[0] * up[0] + Jo[1] * up[1] + Jo[2] * up[2]) - r[2 * o];
         w1 = (Jo[12] * up[0] + Jo[13] * up[1] + Jo[14] * up[2]) - r[2 * o + 1];
+      } else if (MODE == 3) {
+        const double *up = u + 3 * (int64_t)pnt0[o];
+        w0 = Jo[0] * up[0] + Jo[1] * up[1] + Jo[2] * up[2];
+        w1 = Jo[12] * up[0] + Jo[13] * up[1] + Jo[14] * up[2];
       } else {
         w0 = r[2 * o];
         w1 = r[2 * o + 1];
@@ -728,7 +736,175 @@ __global__ __launch_bounds__(BLK) void k_scale_vec(int64_t n, const double *__re
   if (i < n && s[i] != 0) v[i] = divide ? v[i] / s[i] : v[i] * s[i];
 }
 
+// ---- preconditioned conjugate gradients on the reduced camera system (facto = PCG) -------------------------------------
+// S = Hcc + lambda I - W U^-1 W' is never formed: S v = Hcc v + lambda v - sum_a B_a' A_a h_p(a) with h = U^-1 W' v, i.e. the
+// back-substitution pass (by point) followed by the right-hand-side pass (by camera) -- two sweeps over J per product.
+// Preconditioner: the 9 x 9 diagonal blocks of S (block Jacobi).
+
+// diagonal blocks: out45_c = Hcc_c - sum_{a in c} (B_a' A_a) U^-1 (B_a' A_a)'   (packed lower, row-major); one workgroup
+// per camera, the fixed tree of k_cam_blocks
+__global__ __launch_bounds__(BLK) void k_schur_diag(const int *__restrict__ cam_ptr, const int *__restrict__ cam_obs,
+                                                     const int *__restrict__ pnt0, const double *__restrict__ J,
+                                                     const double *__restrict__ Uinv, const double *__restrict__ Hcc,
+                                                     double *__restrict__ out45) {
+  __shared__ double red[BLK / 64][45];
+  const int c = blockIdx.x;
+  double acc[45];
+#pragma unroll
+  for (int i = 0; i < 45; i++) acc[i] = 0;
+  for (int q = cam_ptr[c] + threadIdx.x; q < cam_ptr[c + 1]; q += BLK) {
+    const int64_t o = cam_obs[q];
+    const double *Jo = J + 24 * o;
+    const double *U = Uinv + 6 * (int64_t)pnt0[o];
+    const double a0[3] = {Jo[0], Jo[1], Jo[2]}, a1[3] = {Jo[12], Jo[13], Jo[14]};
+    const double Um[3][3] = {{U[0], U[1], U[2]}, {U[1], U[3], U[4]}, {U[2], U[4], U[5]}};
+    double T[9][3], M[9][3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) T[i][k] = Jo[3 + i] * a0[k] + Jo[15 + i] * a1[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) M[i][k] = (T[i][0] * Um[0][k] + T[i][1] * Um[1][k]) + T[i][2] * Um[2][k];
+    }
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) acc[idx++] += (M[i][0] * T[j][0] + M[i][1] * T[j][1]) + M[i][2] * T[j][2];
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 45; i++) {
+    double v = wave_sum(acc[i]);
+    if (lane == 0) red[wv][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 45)
+    out45[45 * (int64_t)c + threadIdx.x] = Hcc[45 * (int64_t)c + threadIdx.x] -
+                                            (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+
+// Cholesky of blk45_c + lambda I in place (one lane per camera); a non-positive pivot raises the flag
+__global__ __launch_bounds__(BLK) void k_pcg_factor(int64_t ncams, double lambda, double *__restrict__ blk45, int *__restrict__ flag) {
+  const int64_t c = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (c >= ncams) return;
+  double L[9][9];
+  int idx = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) L[i][j] = blk45[45 * c + idx++] + (i == j ? lambda : 0.0);
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    double s = L[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+    if (!(s > 0.0)) bad = true;
+    const double d = sqrt(s), inv = 1.0 / d;
+    L[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < 9; i++) {
+      double t = L[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+      L[i][j] = t * inv;
+    }
+  }
+  idx = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) blk45[45 * c + idx++] = L[i][j];
+  if (bad) *flag = 1;
+}
+
+// z_c = (L L')^-1 r_c
+__global__ __launch_bounds__(BLK) void k_pcg_apply(int64_t ncams, const double *__restrict__ L45, const double *__restrict__ r,
+                                                    double *__restrict__ z) {
+  const int64_t c = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (c >= ncams) return;
+  double L[9][9], y[9];
+  int idx = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) L[i][j] = L45[45 * c + idx++];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    double t = r[9 * c + i];
+#pragma unroll
+    for (int k = 0; k < i; k++) t -= L[i][k] * y[k];
+    y[i] = t / L[i][i];
+  }
+#pragma unroll
+  for (int i = 8; i >= 0; i--) {
+    double t = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 9; k++) t -= L[k][i] * y[k];
+    y[i] = t / L[i][i];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) z[9 * c + i] = y[i];
+}
+
+// q_c = Hcc_c v_c + t_c   (Hcc packed lower; t = sum_a B_a' A_a h with h = -U^-1 W' v, see above); one lane per camera
+__global__ __launch_bounds__(BLK) void k_hcc_mv(int64_t ncams, const double *__restrict__ Hcc, const double *__restrict__ v,
+                                                 const double *__restrict__ t, double *__restrict__ q) {
+  const int64_t c = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (c >= ncams) return;
+  double H[9][9], x[9];
+  int idx = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      H[i][j] = Hcc[45 * c + idx++];
+      H[j][i] = H[i][j];
+    }
+#pragma unroll
+  for (int i = 0; i < 9; i++) x[i] = v[9 * c + i];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) s += H[i][j] * x[j];
+    q[9 * c + i] = s + t[9 * c + i];
+  }
+}
+
+__global__ __launch_bounds__(BLK) void k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                              double *__restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) acc += a[i] * b[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+// y += a x
+__global__ __launch_bounds__(BLK) void k_axpy_s(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+// x += alpha p, r -= alpha q
+__global__ __launch_bounds__(BLK) void k_cg_update(int64_t n, double alpha, const double *__restrict__ pd, const double *__restrict__ q,
+                                                    double *__restrict__ x, double *__restrict__ r) {
+  const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) {
+    x[i] += alpha * pd[i];
+    r[i] -= alpha * q[i];
+  }
+}
+// p = z + beta p
+__global__ __launch_bounds__(BLK) void k_cg_dir(int64_t n, double beta, const double *__restrict__ z, double *__restrict__ pd) {
+  const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) pd[i] = z[i] + beta * pd[i];
+}
+
 }  // namespace
+
 
 static inline unsigned grid_for(int64_t n, int blk) { return (unsigned)((n + blk - 1) / blk); }
 
@@ -933,5 +1109,70 @@ int launch_f16_scale(ba_problem *p, double lambda, double mu, const double *d_jn
     hipLaunchKernelGGL(k_f16_quantize, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->npnts, p->cam0, p->pnt0, d_J,
                        d_r, d_dcol, mu, d_Jq, d_rq);
   BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+// ---- PCG launchers ------------------------------------------------------------------------------------------------------
+// t_c = sum_a B_a' A_a h_p(a)
+int launch_wuw(ba_problem *p, const double *d_J, const double *d_h, double *d_t, hipStream_t st) {
+  if (p->ncams == 0) return BA_OK;
+  ProfScope ps(p, PC_SCHUR_RHS, st);
+  if (staged_on())
+    hipLaunchKernelGGL(k_cam_blocks_st<3>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
+                       (const double *)nullptr, d_h, (double *)nullptr, d_t);
+  else
+    hipLaunchKernelGGL(k_cam_blocks<3>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
+                       (const double *)nullptr, d_h, (double *)nullptr, d_t);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+int launch_schur_diag(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_Hcc, double *d_blk45, hipStream_t st) {
+  if (p->ncams == 0) return BA_OK;
+  ProfScope ps(p, PC_SCHUR_S, st);
+  hipLaunchKernelGGL(k_schur_diag, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J, d_Uinv, d_Hcc,
+                     d_blk45);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+int launch_pcg_factor(ba_problem *p, double lambda, double *d_blk45, int *d_flag, hipStream_t st) {
+  hipLaunchKernelGGL(k_pcg_factor, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, lambda, d_blk45, d_flag);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+int launch_pcg_apply(ba_problem *p, const double *d_L45, const double *d_r, double *d_z, hipStream_t st) {
+  hipLaunchKernelGGL(k_pcg_apply, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_L45, d_r, d_z);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+int launch_hcc_mv(ba_problem *p, const double *d_Hcc, const double *d_v, const double *d_t, double *d_q, hipStream_t st) {
+  hipLaunchKernelGGL(k_hcc_mv, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_Hcc, d_v, d_t, d_q);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+int launch_dot(ba_problem *p, int64_t n, const double *d_a, const double *d_b, double *d_partial, double *d_scal, int slot,
+               hipStream_t st) {
+  ProfScope ps(p, PC_REDUCE, st);
+  int nb = (int)((n + BLK - 1) / BLK);
+  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_dot, dim3(nb), dim3(BLK), 0, st, n, d_a, d_b, d_partial);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLK), 0, st, nb, d_partial, d_scal, slot);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+int launch_axpy_s(ba_problem *p, int64_t n, double a, const double *d_x, double *d_y, hipStream_t st) {
+  if (n == 0) return BA_OK;
+  hipLaunchKernelGGL(k_axpy_s, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, a, d_x, d_y);
+  return BA_OK;
+}
+int launch_cg_update(ba_problem *p, int64_t n, double alpha, const double *d_p, const double *d_q, double *d_x, double *d_r,
+                     hipStream_t st) {
+  if (n == 0) return BA_OK;
+  hipLaunchKernelGGL(k_cg_update, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, alpha, d_p, d_q, d_x, d_r);
+  return BA_OK;
+}
+int launch_cg_dir(ba_problem *p, int64_t n, double beta, const double *d_z, double *d_p, hipStream_t st) {
+  if (n == 0) return BA_OK;
+  hipLaunchKernelGGL(k_cg_dir, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, beta, d_z, d_p);
   return BA_OK;
 }

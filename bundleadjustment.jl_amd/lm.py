@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from .model import BALNLPModel, FeasibilityResidual
 
-_FACTO = {"LDL": 0, "QR": 1}
+_FACTO = {"LDL": 0, "QR": 1, "PCG": 2}
 _NORM = {"None": 0, "J": 1, "A": 2}
 _PERM = ("AMD", "Metis")
 
@@ -39,6 +39,7 @@ class GenericExecutionStats:
     n_factor: int = 0
     lambda_final: float = 0.0
     log: list = field(default_factory=list)
+    n_cg: int = 0  # facto = :PCG: conjugate-gradient iterations over the whole solve
 
     def __str__(self):
         return (f"Generic Execution stats\n  status: {self.status}\n  objective value: {self.objective!r}\n"
@@ -54,10 +55,10 @@ def _sym(s):
 def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=None, facto_type=None,
                         restol=None, satol=None, srtol=None, oatol=None, ortol=None, atol=None, rtol=None,
                         nu_d=None, nu_m=None, lam=None, delta_d=None, ite_max=None, max_time=None, verbose=False,
-                        log=True):
+                        log=True, pcg_tol=None, pcg_max_iter=None):
     facto, perm, normalize = _sym(facto), _sym(perm), _sym(normalize)
     if facto not in _FACTO:
-        raise ValueError(f"facto must be :QR or :LDL, got {facto!r}")
+        raise ValueError(f"facto must be :QR, :LDL or :PCG (extension: matrix-free CG on the reduced camera system), got {facto!r}")
     if perm not in _PERM:
         raise ValueError(f"perm must be :AMD or :Metis, got {perm!r}")
     if normalize not in _NORM:
@@ -88,7 +89,8 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
     o = _lib.LMOpts(variant=variant, facto=_FACTO[facto], normalize=_NORM[normalize], linesearch=int(bool(linesearch)),
                     facto_type=ft, ite_max=-1 if ite_max is None else int(ite_max), verbose=int(verbose), x_f32=int(xf32),
                     restol=d(restol), satol=d(satol), srtol=d(srtol), oatol=d(oatol), ortol=d(ortol), atol=d(atol),
-                    rtol=d(rtol), nu_d=d(nu_d), nu_m=d(nu_m), lam=d(lam), delta_d=d(delta_d), max_time=d(max_time))
+                    rtol=d(rtol), nu_d=d(nu_d), nu_m=d(nu_m), lam=d(lam), delta_d=d(delta_d), max_time=d(max_time),
+                    pcg_tol=d(pcg_tol), pcg_max_iter=-1 if pcg_max_iter is None else int(pcg_max_iter))
     st = _lib.LMStats()
     rows = []
 
@@ -104,7 +106,7 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
     out = GenericExecutionStats(status=_lib.STATUS[st.status], solution=x0.astype(nlp.T) if xf32 else x0, objective=st.objective, iter=st.iter,
                                 elapsed_time=st.elapsed_s, loop_time=st.loop_s, n_accepted=st.n_accepted,
                                 n_rejected=st.n_rejected, n_residual=st.n_residual, n_jacobian=st.n_jacobian,
-                                n_factor=st.n_factor, lambda_final=st.lambda_final, log=rows)
+                                n_factor=st.n_factor, lambda_final=st.lambda_final, log=rows, n_cg=st.n_cg)
     if variant == 1:
         out.dual_feas = st.dual_feas    # lm.jl:415
     else:
@@ -112,13 +114,19 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
     return out
 
 
-def lm_step(nlp, x, lam, want_jtr=True, facto_type=None):
+def lm_step(nlp, x, lam, want_jtr=True, facto_type=None, pcg=None):
     """One linear LM step from (x, lambda): delta, 1/2|J delta + r|^2, J'r  (ba_lm_step; facto_type=np.float32:
-    ba_lm_step_f32, the reduced camera system factored in Float32 as src/lm.jl:170-173 does)."""
+    ba_lm_step_f32, the reduced camera system factored in Float32 as src/lm.jl:170-173 does; pcg=(tol, max_iter):
+    ba_lm_step_pcg, the step by preconditioned CG -- the CG iteration count is then appended to the result)."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     delta = np.empty(nlp.meta.nvar)
     jtr = np.empty(nlp.meta.nvar) if want_jtr else None
     half = C.c_double(0)
+    if pcg is not None:
+        its = C.c_int(0)
+        _lib.check(_lib.lib().ba_lm_step_pcg(nlp.handle, _lib.ptr(x), float(lam), float(pcg[0]), int(pcg[1]), _lib.ptr(delta),
+                                             C.byref(half), _lib.ptr(jtr) if want_jtr else None, C.byref(its)))
+        return delta, half.value, jtr, its.value
     f32 = facto_type is not None and np.dtype(facto_type) == np.float32
     fn = _lib.lib().ba_lm_step_f32 if f32 else _lib.lib().ba_lm_step
     _lib.check(fn(nlp.handle, _lib.ptr(x), float(lam), _lib.ptr(delta), C.byref(half), _lib.ptr(jtr) if want_jtr else None))

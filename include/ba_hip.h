@@ -119,7 +119,11 @@ typedef struct ba_lm_opts {
   int variant;    /* 0 LevenbergMarquardt.jl, 1 lm.jl */
   int facto;      /* 0 :LDL, 1 :QR -- both are served by the same device solve of (J'J + lambda I) delta = -J'r; what
                    *    survives of the branch: inside the line search :QR re-evaluates |J delta + r|^2 (src/lm.jl:273)
-                   *    while :LDL uses the recursion of src/lm.jl:277 (they differ for delta_d != 2) */
+                   *    while :LDL uses the recursion of src/lm.jl:277 (they differ for delta_d != 2).
+                   *    2 :PCG (an extension, no counterpart in the reference: SURVEY 8f) -- the reduced camera system is
+                   *    never formed; block-Jacobi preconditioned conjugate gradients apply it through J (two sweeps per
+                   *    iteration) to |residual| <= pcg_tol |right-hand side|: an inexact LM step, judged by the same
+                   *    accept test; Float64, no column scaling, model value as :QR */
   int normalize;  /* 0 :None, 1 :J, 2 :A  (src/lma_aux.jl:102-178) */
   int linesearch; /* lm.jl only, src/lm.jl:264-295 */
   int facto_type; /* lm.jl only, `facto_type` keyword: 0 = Float64 (the default for a Float64 model), 1 = Float32
@@ -134,6 +138,9 @@ typedef struct ba_lm_opts {
   double restol, satol, srtol, oatol, ortol, atol, rtol; /* <0: default */
   double nu_d, nu_m, lambda, delta_d;                    /* <=0: default (3, 3, 30 | 0.1, 2) */
   double max_time;                                        /* <=0: 3600 (inert in the reference, lm.jl:33,115,382) */
+  double pcg_tol;                                         /* facto = 2: relative residual of the CG solve, <=0: 1e-8 */
+  int pcg_max_iter;                                       /* facto = 2: CG iterations per LM step, <=0: 1000 */
+  int reserved1;
 } ba_lm_opts;
 
 typedef struct ba_lm_stats {
@@ -141,7 +148,7 @@ typedef struct ba_lm_stats {
   int iter;    /* LM iterations (lm.jl:127 / LevenbergMarquardt.jl:240) */
   int n_accepted, n_rejected;
   int n_residual, n_jacobian, n_factor;
-  int reserved0;
+  int n_cg;    /* facto = 2: CG iterations over the whole solve */
   double objective;    /* 1/2 |r|^2 at the returned x */
   double dual_feas;    /* |J' r| (lm.jl:415; primal_feas in the old variant, LevenbergMarquardt.jl:384) */
   double lambda_final;
@@ -196,6 +203,9 @@ int ba_lm_step(ba_problem *p, const double *x, double lambda, double *delta, dou
  * rounded to Float32, factored and solved there; everything else stays Float64 */
 int ba_lm_step_f32(ba_problem *p, const double *x, double lambda, double *delta, double *half_sq_model,
                    double *jtr /* nvar or NULL */);
+/* the same step by facto = PCG (see ba_lm_opts.facto): tol / max_iter as pcg_tol / pcg_max_iter; cg_iters_out may be NULL */
+int ba_lm_step_pcg(ba_problem *p, const double *x, double lambda, double tol, int max_iter, double *delta,
+                   double *half_sq_model, double *jtr, int *cg_iters_out);
 
 /* ---- per-kernel timing (hipEvent pairs on the handle's stream) ------------------------------------ */
 int ba_profile_enable(ba_problem *p, int on);

@@ -52,6 +52,9 @@ struct BaLmOpts
   lambda :: Cdouble
   delta_d :: Cdouble
   max_time :: Cdouble
+  pcg_tol :: Cdouble
+  pcg_max_iter :: Cint
+  reserved1 :: Cint
 end
 
 # struct ba_lm_stats (include/ba_hip.h)
@@ -63,7 +66,7 @@ mutable struct BaLmStats
   n_residual :: Cint
   n_jacobian :: Cint
   n_factor :: Cint
-  reserved0 :: Cint
+  n_cg :: Cint
   objective :: Cdouble
   dual_feas :: Cdouble
   lambda_final :: Cdouble

@@ -17,8 +17,10 @@ end
 
 function _ba_lm(model, variant :: Int, facto :: Symbol, perm :: Symbol, normalize :: Symbol, linesearch :: Bool,
                 x :: AbstractVector, facto_type :: DataType, restol, satol, srtol, oatol, ortol, atol, rtol, νd, νm, λ, δd,
-                ite_max :: Int, max_time :: Real)
-  facto in (:QR, :LDL) || error("facto must be :QR or :LDL")
+                ite_max :: Int, max_time :: Real, pcg_tol :: Real = -1.0, pcg_max_iter :: Int = -1)
+  # :PCG is an extension of the HIP path (no counterpart in the reference): matrix-free conjugate gradients on the reduced
+  # camera system, include/ba_hip.h, ba_lm_opts.facto
+  facto in (:QR, :LDL, :PCG) || error("facto must be :QR, :LDL or :PCG")
   perm in (:AMD, :Metis) || error("perm must be :AMD or :Metis")   # kept for the signature: the device elimination order is fixed
   normalize in (:None, :J, :A) || error("normalize must be :None, :J or :A")
   nlp = model.nlp                       # the BALNLPModel inside FeasibilityResidual (src/solve_ba.jl:25)
@@ -26,9 +28,10 @@ function _ba_lm(model, variant :: Int, facto :: Symbol, perm :: Symbol, normaliz
   T in (Float64, Float32) || error("the HIP path iterates in Float64 or Float32")
   ft = facto_type == T ? 0 : facto_type == Float32 ? 1 : facto_type == Float16 ? 2 : error("facto_type must be Float64, Float32 or Float16")
   (T == Float32 && ft == 0 && variant == 1) && (ft = 1)   # eltype(x) = Float32: facto_type defaults to it (src/lm.jl:20)
-  o = BaLmOpts(variant, facto == :QR ? 1 : 0, normalize == :None ? 0 : normalize == :J ? 1 : 2, linesearch ? 1 : 0, ft,
+  o = BaLmOpts(variant, facto == :QR ? 1 : facto == :PCG ? 2 : 0, normalize == :None ? 0 : normalize == :J ? 1 : 2, linesearch ? 1 : 0, ft,
                ite_max, 0, T == Float32 ? 1 : 0, _tol(restol), _tol(satol), _tol(srtol), _tol(oatol), _tol(ortol),
-               _tol(atol), _tol(rtol), _tol(νd), _tol(νm), _tol(λ), _tol(δd), Float64(max_time))
+               _tol(atol), _tol(rtol), _tol(νd), _tol(νm), _tol(λ), _tol(δd), Float64(max_time), Float64(pcg_tol),
+               Cint(pcg_max_iter), Cint(0))
   st = BaLmStats()
   xd = Vector{Float64}(x)               # the ABI carries the iterate as doubles (exact for Float32 values)
   cb = @cfunction(_ba_log_row, Cvoid, (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint))
@@ -58,9 +61,9 @@ function Levenberg_Marquardt(model :: AbstractNLSModel, facto :: Symbol, perm ::
                              x :: AbstractVector = copy(model.meta.x0), facto_type :: DataType = eltype(x),
                              restol = nothing, satol = nothing, srtol = nothing, oatol = nothing, ortol = nothing,
                              atol = nothing, rtol = nothing, νd = nothing, νm = nothing, λ = nothing, δd = nothing,
-                             ite_max :: Int = 200, max_time :: Int = 3600)
+                             ite_max :: Int = 200, max_time :: Int = 3600, pcg_tol :: Real = -1.0, pcg_max_iter :: Int = -1)
   return _ba_lm(model, 1, facto, perm, normalize, linesearch, x, facto_type, restol, satol, srtol, oatol, ortol, atol, rtol,
-                νd, νm, λ, δd, ite_max, max_time)
+                νd, νm, λ, δd, ite_max, max_time, pcg_tol, pcg_max_iter)
 end
 
 "src/LevenbergMarquardt.jl:16-26 -- the 4-argument method src/solve_ba.jl:26 calls (no linesearch, no facto_type)"

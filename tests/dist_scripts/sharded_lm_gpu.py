@@ -44,14 +44,23 @@ def main():
     ba.parallel.CameraBlockReducer(wn)
     dw, halfw, _ = ba.lm_step(wn, wl[3], 10.0)
     dw = ba.parallel.gather_solution(dw, winfo, wide["ncams"])
+    # facto = :PCG on the shards: the product S v is all-reduced once per CG iteration, everything else is replicated
+    dpcg, halfpcg, _, its = ba.lm_step(wn, wl[3], 10.0, pcg=(1e-12, 5000))
+    dpcg = ba.parallel.gather_solution(dpcg, winfo, wide["ncams"])
+    stp = ba.Levenberg_Marquardt(ba.FeasibilityResidual(wn), "PCG", "AMD", "None", False, ite_max=3, pcg_tol=1e-10)
+    out.update(pcg_its=its, pcg_lm_objective=stp.objective, pcg_lm_cg=stp.n_cg)
     wn.close()
     if rank == 0:
         wf = ba.BALNLPModel(arrays=warr, device=0)
         dw_ref, halfw_ref, _ = ba.lm_step(wf, warr[3], 10.0)
+        stp1 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(wf), "PCG", "AMD", "None", False, ite_max=3, pcg_tol=1e-10)
+        out["pcg_lm_objective_ref"] = stp1.objective
         wf.close()
         out["step_wide"] = float(np.linalg.norm(dw - dw_ref) / np.linalg.norm(dw_ref))
         out["half_wide"] = float(abs(halfw - halfw_ref) / halfw_ref)
         out["wide_hex"] = [float(v).hex() for v in dw[-9 * wide["ncams"]:]]
+        out["step_pcg"] = float(np.linalg.norm(dpcg - dw_ref) / np.linalg.norm(dw_ref))
+        out["half_pcg"] = float(abs(halfpcg - halfw_ref) / halfw_ref)
     # (b) complete LM runs
     prob = ba.synthetic.make_problem(14, 600, 2700, seed=5)
     arrays = ba.synthetic.as_arrays(prob)

@@ -67,6 +67,9 @@ def _check_sharded(res):
     assert res["step_f64"] <= 1e-9 and res["half_f64"] <= 1e-10 and res["jtr_f64"] <= 1e-12
     assert res["step_f32"] <= 5e-3 and res["jtr_f32"] <= 1e-12
     assert res["step_wide"] <= 1e-9 and res["half_wide"] <= 1e-10
+    # facto = :PCG on the shards: the tightly solved CG step is the direct step; three LM iterations as on one rank
+    assert 0 < res["pcg_its"] < 5000 and res["step_pcg"] <= 1e-8 and res["half_pcg"] <= 1e-9
+    assert abs(res["pcg_lm_objective"] - res["pcg_lm_objective_ref"]) <= 1e-9 * res["pcg_lm_objective_ref"] and res["pcg_lm_cg"] > 0
     assert res["step_calls"] > 0
     assert res["iter"] == res["ref_iter"] and res["status"] == res["ref_status"] and res["log_equal"]
     assert abs(res["objective"] - res["ref_objective"]) <= 1e-9 * res["ref_objective"]

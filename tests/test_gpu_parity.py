@@ -741,3 +741,61 @@ def test_dense_ldl_hoisted_schedule_and_its_fallback(ba, gpu_ok):
             assert r.returncode == 0, r.stdout + r.stderr
             rel = float([l for l in r.stdout.splitlines() if l.startswith("REL")][0].split()[1])
             assert rel < 1e-12, (n, extra, rel)
+
+
+# ---- facto = :PCG (extension, SURVEY 8f: matrix-free conjugate gradients on the reduced camera system) ----------------------
+@pytest.mark.parametrize("lam", [1e3, 30.0, 1.0])
+def test_pcg_step_vs_oracle(ba, orc, small_prob, nlp_small, lam):
+    """The reference has no iterative branch: what pins the PCG step is the DIRECT step of the oracle (ldl_aux.jl restated)
+    from the same (x, lambda) -- solved to a relative residual of 1e-13 the CG step must reproduce it to 1e-8; a loose
+    tolerance gives an inexact step whose DAMPED model value 1/2|J d + r|^2 + lambda/2 |d|^2 is larger, never smaller."""
+    p = small_prob
+    rc, d_ref, dr_ref, _ = orc.lm_step(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"], lam)
+    assert rc == 0
+    d, half, jtr, its = ba.lm_step(nlp_small, p["x0"], lam, pcg=(1e-13, 5000))
+    rel = np.linalg.norm(d - d_ref) / np.linalg.norm(d_ref)
+    half_ref = 0.5 * dr_ref @ dr_ref
+    print(f"lambda {lam}: {its} CG iterations, |d - d_ref|/|d_ref| = {rel:.2e}")
+    assert 0 < its < 5000 and rel <= 1e-8 and abs(half - half_ref) <= 1e-9 * half_ref
+    d2, half2, _, its2 = ba.lm_step(nlp_small, p["x0"], lam, pcg=(1e-2, 5000))
+    damped, damped_ref = half2 + 0.5 * lam * (d2 @ d2), half_ref + 0.5 * lam * (d_ref @ d_ref)
+    assert its2 < its and damped >= damped_ref * (1 - 1e-12)
+    # the direct entry still works on the same handle afterwards (the flag is per call)
+    d3, half3, _ = ba.lm_step(nlp_small, p["x0"], lam)
+    assert np.linalg.norm(d3 - d_ref) <= 1e-9 * np.linalg.norm(d_ref)
+
+
+def test_pcg_step_many_cameras(ba, gpu_ok):
+    """600 cameras (n = 5400): the CG step against the device's own direct step (itself checked against numpy and the oracle
+    above) -- the Schur complement is applied through J, the direct path assembles and factors it."""
+    big = ba.synthetic.make_problem(600, 4000, 30000, seed=3)
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(big))
+    d_ref, half_ref, _ = ba.lm_step(m, big["x0"], 10.0)
+    d, half, _, its = ba.lm_step(m, big["x0"], 10.0, pcg=(1e-12, 5000))
+    rel = np.linalg.norm(d - d_ref) / np.linalg.norm(d_ref)
+    print(f"{its} CG iterations, |d - d_ref|/|d_ref| = {rel:.2e}")
+    assert its < 5000 and rel <= 1e-8 and abs(half - half_ref) <= 1e-9 * half_ref
+    m.close()
+
+
+def test_lm_pcg_run_reaches_the_direct_minimum(ba, small_prob, gpu_ok):
+    """Complete lm.jl runs with facto = :PCG: solved tightly the run follows the :LDL run (same iterations, same accept /
+    reject sequence, objective to 1e-8); with the default tolerance (1e-8) and a loose one (1e-2: truncated Newton) it still
+    ends at the same minimum."""
+    p = small_prob
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    fr = ba.FeasibilityResidual(m)
+    ref = ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False)
+    tight = ba.Levenberg_Marquardt(fr, "PCG", "AMD", "None", False, pcg_tol=1e-13, pcg_max_iter=5000)
+    print("LDL", ref.iter, ref.objective, "PCG tight", tight.iter, tight.objective, tight.n_cg)
+    assert tight.iter == ref.iter and tight.status == ref.status and tight.n_cg > 0
+    assert [r[7] for r in tight.log] == [r[7] for r in ref.log]
+    assert abs(tight.objective - ref.objective) <= 1e-8 * ref.objective
+    for kw in ({}, {"pcg_tol": 1e-2}):
+        st = ba.Levenberg_Marquardt(fr, "PCG", "AMD", "None", False, **kw)
+        print("PCG", kw, st.iter, st.objective, st.n_cg, st.status)
+        assert st.status in ("first_order", "small_residual", "acceptable", "small_step")
+        assert abs(st.objective - ref.objective) <= 1e-5 * ref.objective
+    with pytest.raises(Exception):
+        ba.Levenberg_Marquardt(fr, "PCG", "AMD", "None", False, facto_type=np.float16)
+    m.close()
