@@ -63,6 +63,7 @@ def parse():
                     help="ldl: the reference's direct branch (the default line); pcg: the matrix-free CG extension "
                          "(--pcg-tol: its relative residual)")
     ap.add_argument("--pcg-tol", type=float, default=1e-8)
+    ap.add_argument("--no-pcg", action="store_true", help="skip the secondary facto = :PCG measurement")
     ap.add_argument("--backend", default=os.environ.get("BA_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend: nccl (= RCCL, default) or gloo (host-staged all-reduce; rehearsal only)")
     ap.add_argument("--single-device", action="store_true",
@@ -159,6 +160,22 @@ def main():
 
     elapsed = max_over_ranks(elapsed)
     assert st.iter == args.steps, (st.iter, args.steps)
+
+    # ---- the same K iterations by the matrix-free CG extension (facto = :PCG, relative residual 1e-8), reported beside the
+    # headline (which stays on the reference's direct branch): the path that scales with the number of GPUs ------------------
+    pcg_line = None
+    if FACTO != "PCG" and not args.no_pcg:
+        def lm_pcg(k):
+            return ba.Levenberg_Marquardt(fr, "PCG", "AMD", "None", False, ite_max=k - 1, restol=0.0, satol=0.0, srtol=0.0, oatol=0.0,
+                                          ortol=0.0, atol=0.0, rtol=0.0, log=False, pcg_tol=1e-8)
+        lm_pcg(max(1, min(2, args.warmup)))
+        barrier()
+        t2 = time.perf_counter()
+        stp = lm_pcg(args.steps)
+        barrier()
+        el2 = max_over_ranks(time.perf_counter() - t2)
+        pcg_line = {"metric": "LM iterations/s, facto = :PCG (pcg_tol 1e-8)", "value": stp.iter / el2, "ms_per_step": 1e3 * el2 / max(1, stp.iter),
+                    "n_cg": stp.n_cg, "objective": stp.objective, "objective_direct": st.objective}
 
     # ---- Jacobian throughput: jac_coord on device-resident x / vals, events on the launch stream ---------------------
     stream = torch.cuda.Stream()  # a real (non-null) stream: the library treats a null stream as "the handle's own"
@@ -332,6 +349,7 @@ def main():
             "jacobian_ms": jac_ms,
             "lm": {"accepted": st.n_accepted, "rejected": st.n_rejected, "objective": st.objective,
                    "n_jacobian": st.n_jacobian, "n_factor": st.n_factor, "n_cg": st.n_cg, "loop_s": st.loop_time},
+            "pcg": pcg_line,
             "roofline": roof,
             "roofline_jacobian": roof_jac,
             "roofline_residual": roof_res,
