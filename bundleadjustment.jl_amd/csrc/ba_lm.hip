@@ -417,27 +417,30 @@ static int ensure_pcg(ba_problem *p, LMWorkFull *w) {
   BA_CHECK(dm(&w->cgh, 3 * p->npnts));
   BA_CHECK(dm(&w->zero3, 3 * p->npnts));
   BA_CHECK(dm(&w->blk45, 45 * p->ncams));
-  BA_CHECK(dm(&w->cg_scal, 4));
-  BA_HIP_CHECK(hipHostMalloc((void **)&w->h_cg, 4 * sizeof(double)));
+  BA_CHECK(dm(&w->cg_scal, 8));
+  BA_HIP_CHECK(hipHostMalloc((void **)&w->h_cg, 8 * sizeof(double)));
   return BA_OK;
 }
 
-// q = S v (partial sums reduced over the ranks, then the damping, which every rank adds to the full sum)
+// q = S v: the point sweep, then the camera sweep (which adds Hcc v and, on one rank, the damping); on several ranks the
+// partial products are summed by one all-reduce and every rank adds the damping to the full sum
 static int pcg_matvec(ba_problem *p, LMWorkFull *w, double lambda, const double *v, double *q, hipStream_t st) {
+  const bool shared = p->comm.active();
   BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->zero3, v, w->cgh, st));  // h = -U^-1 W' v
-  BA_CHECK(launch_wuw(p, w->J, w->cgh, w->cgt, st));                      // t = W h = -W U^-1 W' v
-  BA_CHECK(launch_hcc_mv(p, w->Hcc, v, w->cgt, q, st));                   // Hcc v + t
+  BA_CHECK(launch_wuw(p, w->J, w->cgh, w->Hcc, v, shared ? 0.0 : lambda, q, st));
+  if (!shared) return BA_OK;
   BA_CHECK(comm_allreduce(p, q, w->n, st));
   return launch_axpy_s(p, w->n, lambda, v, q, st);
 }
 
 static int pcg_fetch(LMWorkFull *w, hipStream_t st) {
-  BA_HIP_CHECK(hipMemcpyAsync(w->h_cg, w->cg_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+  BA_HIP_CHECK(hipMemcpyAsync(w->h_cg, w->cg_scal, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
   BA_HIP_CHECK(hipStreamSynchronize(st));
   return BA_OK;
 }
 
-// S x = rhs (w->rhs in, solution out) to |r| <= pcg_tol |rhs| or pcg_maxit iterations
+// S x = rhs (w->rhs in, solution out) to |r| <= pcg_tol |rhs| or pcg_maxit iterations.  alpha and beta are formed on the
+// device (k_cg_alpha, k_cg_beta_dir); the host reads the scalars once per iteration, for the stopping test.
 static int pcg_solve(ba_problem *p, LMWorkFull *w, double lambda, hipStream_t st) {
   BA_CHECK(ensure_pcg(p, w));
   const int64_t n = w->n;
@@ -448,31 +451,22 @@ static int pcg_solve(ba_problem *p, LMWorkFull *w, double lambda, hipStream_t st
   BA_CHECK(launch_pcg_factor(p, lambda, w->blk45, w->ldl.flag, st));  // a block that is not positive definite -> SQDException
   BA_HIP_CHECK(hipMemsetAsync(w->cgx, 0, (size_t)n * sizeof(double), st));
   BA_HIP_CHECK(hipMemcpyAsync(w->cgr, w->rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BA_CHECK(launch_pcg_apply(p, w->blk45, w->cgr, w->cgz, st));
-  BA_HIP_CHECK(hipMemcpyAsync(w->cgp, w->cgz, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BA_CHECK(launch_dot(p, n, w->cgr, w->cgz, w->partial, w->cg_scal, 2, st));
-  BA_CHECK(launch_dot(p, n, w->cgr, w->cgr, w->partial, w->cg_scal, 1, st));
+  BA_CHECK(launch_cg_step(p, w->cg_scal, w->blk45, w->cgp, w->cgq, w->cgx, w->cgr, w->cgz, w->cgt, 1, st));  // z, r.r, r.z
+  BA_CHECK(launch_cg_beta_dir(p, n, w->cgt, w->cg_scal, w->cgz, w->cgp, 1, st));                              // p = z
   BA_CHECK(pcg_fetch(w, st));
-  double rz = w->h_cg[2];
   const double b2 = w->h_cg[1];
   int it = 0;
-  if (b2 > 0 && rz == rz) {
+  if (b2 > 0 && w->h_cg[2] == w->h_cg[2]) {
     for (it = 1; it <= maxit; it++) {
       BA_CHECK(pcg_matvec(p, w, lambda, w->cgp, w->cgq, st));
-      BA_CHECK(launch_dot(p, n, w->cgp, w->cgq, w->partial, w->cg_scal, 0, st));
+      BA_CHECK(launch_cg_alpha(p, n, w->cgp, w->cgq, w->cg_scal, st));
+      BA_CHECK(launch_cg_step(p, w->cg_scal, w->blk45, w->cgp, w->cgq, w->cgx, w->cgr, w->cgz, w->cgt, 0, st));
+      BA_CHECK(launch_cg_beta_dir(p, n, w->cgt, w->cg_scal, w->cgz, w->cgp, 0, st));
       BA_CHECK(pcg_fetch(w, st));
-      const double pq = w->h_cg[0];
-      if (!(pq > 0)) break;  // S not positive definite along p (or NaN): keep what there is, the LM test judges the step
-      const double alpha = rz / pq;
-      BA_CHECK(launch_cg_update(p, n, alpha, w->cgp, w->cgq, w->cgx, w->cgr, st));
-      BA_CHECK(launch_pcg_apply(p, w->blk45, w->cgr, w->cgz, st));
-      BA_CHECK(launch_dot(p, n, w->cgr, w->cgr, w->partial, w->cg_scal, 1, st));
-      BA_CHECK(launch_dot(p, n, w->cgr, w->cgz, w->partial, w->cg_scal, 2, st));
-      BA_CHECK(pcg_fetch(w, st));
-      const double rr = w->h_cg[1], rz_new = w->h_cg[2];
-      if (!(rr == rr) || rr <= w->pcg_tol * w->pcg_tol * b2) break;
-      BA_CHECK(launch_cg_dir(p, n, rz_new / rz, w->cgz, w->cgp, st));
-      rz = rz_new;
+      const double pq = w->h_cg[0], rr = w->h_cg[1];
+      // p.q <= 0: S not positive definite along p (or NaN) -- alpha was 0, nothing moved; keep what there is, the LM test
+      // judges the step
+      if (!(pq > 0) || !(rr == rr) || rr <= w->pcg_tol * w->pcg_tol * b2) break;
     }
   }
   w->n_cg += it < maxit ? it : maxit;

@@ -74,14 +74,13 @@ int launch_scale_scalar(ba_problem *p, int64_t n, double *d_v, double alpha, hip
 int launch_scale_vec(ba_problem *p, int64_t n, const double *d_s, double *d_v, int divide, hipStream_t st);
 
 // preconditioned conjugate gradients on the reduced camera system (facto = PCG; ba_normal_kernels.hip)
-int launch_wuw(ba_problem *p, const double *d_J, const double *d_h, double *d_t, hipStream_t st);
+int launch_wuw(ba_problem *p, const double *d_J, const double *d_h, const double *d_Hcc, const double *d_v, double lam, double *d_q,
+               hipStream_t st);
 int launch_schur_diag(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_Hcc, double *d_blk45, hipStream_t st);
 int launch_pcg_factor(ba_problem *p, double lambda, double *d_blk45, int *d_flag, hipStream_t st);
-int launch_pcg_apply(ba_problem *p, const double *d_L45, const double *d_r, double *d_z, hipStream_t st);
-int launch_hcc_mv(ba_problem *p, const double *d_Hcc, const double *d_v, const double *d_t, double *d_q, hipStream_t st);
-int launch_dot(ba_problem *p, int64_t n, const double *d_a, const double *d_b, double *d_partial, double *d_scal, int slot,
-               hipStream_t st);
 int launch_axpy_s(ba_problem *p, int64_t n, double a, const double *d_x, double *d_y, hipStream_t st);
-int launch_cg_update(ba_problem *p, int64_t n, double alpha, const double *d_p, const double *d_q, double *d_x, double *d_r,
-                     hipStream_t st);
-int launch_cg_dir(ba_problem *p, int64_t n, double beta, const double *d_z, double *d_p, hipStream_t st);
+int launch_cg_alpha(ba_problem *p, int64_t n, const double *d_p, const double *d_q, double *d_cg, hipStream_t st);
+int launch_cg_step(ba_problem *p, const double *d_cg, const double *d_L45, const double *d_p, const double *d_q, double *d_x,
+                   double *d_r, double *d_z, double *d_partial, int first, hipStream_t st);
+int launch_cg_beta_dir(ba_problem *p, int64_t n, const double *d_partial, double *d_cg, const double *d_z, double *d_p, int first,
+                       hipStream_t st);

@@ -61,12 +61,12 @@ __global__ __launch_bounds__(BLK) void k_point_blocks(int64_t npnts, const int *
 
 // ---- camera side: one workgroup per camera, fixed-order tree ----------------------------------------------
 // MODE 0: Hcc (45, packed lower row-major) and gc = B' r (9).   MODE 1: gc only.
-// MODE 2: rhs = sum_a B_a' (A_a u_p(a) - r_a)   (u = U^-1 gp per point).   MODE 3: sum_a B_a' A_a u_p(a) (PCG matvec).
+// MODE 2: rhs = sum_a B_a' (A_a u_p(a) - r_a)   (u = U^-1 gp per point).   MODE 3 (PCG product): Hcc_c x_c + lam x_c + sum_a B_a' A_a u_p(a), x in `r`.
 template <int MODE>
 __global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_ptr, const int *__restrict__ cam_obs,
                                                      const int *__restrict__ pnt0, const double *__restrict__ J,
                                                      const double *__restrict__ r, const double *__restrict__ u,
-                                                     double *__restrict__ Hcc, double *__restrict__ out9) {
+                                                     double *__restrict__ Hcc, double *__restrict__ out9, double lam = 0.0) {
   constexpr int NACC = (MODE == 0) ? 54 : 9;
   __shared__ double red[BLK / 64][NACC];
   const int c = blockIdx.x;
@@ -120,6 +120,14 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_
     if (MODE == 0) {
       if (threadIdx.x < 45) Hcc[45 * (int64_t)c + threadIdx.x] = v;
       else out9[9 * (int64_t)c + threadIdx.x - 45] = v;
+    } else if (MODE == 3) {  // PCG product: + Hcc_c x_c + lam x_c, x handed over in `r` (Hcc packed lower, read only)
+      const int i = threadIdx.x;
+      const double *x = r + 9 * (int64_t)c;
+      const double *H = Hcc + 45 * (int64_t)c;
+      double s = 0;
+#pragma unroll
+      for (int j = 0; j < 9; j++) s += H[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * x[j];
+      out9[9 * (int64_t)c + i] = (s + v) + lam * x[i];
     } else {
       out9[9 * (int64_t)c + threadIdx.x] = v;
     }
@@ -174,7 +182,7 @@ template <int MODE>
 __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ cam_ptr, const int *__restrict__ cam_obs,
                                                         const int *__restrict__ pnt0, const double *__restrict__ J,
                                                         const double *__restrict__ r, const double *__restrict__ u,
-                                                        double *__restrict__ Hcc, double *__restrict__ out9) {
+                                                        double *__restrict__ Hcc, double *__restrict__ out9, double lam = 0.0) {
   constexpr int NACC = (MODE == 0) ? 54 : 9;
   __shared__ double slots[(BLK / 64) * ST_WAVE_ELEMS];
   __shared__ double red[BLK / 64][NACC];
@@ -236,6 +244,14 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ c
     if (MODE == 0) {
       if (threadIdx.x < 45) Hcc[45 * (int64_t)c + threadIdx.x] = v;
       else out9[9 * (int64_t)c + threadIdx.x - 45] = v;
+    } else if (MODE == 3) {  // PCG product: + Hcc_c x_c + lam x_c, x handed over in `r` (Hcc packed lower, read only)
+      const int i = threadIdx.x;
+      const double *x = r + 9 * (int64_t)c;
+      const double *H = Hcc + 45 * (int64_t)c;
+      double s = 0;
+#pragma unroll
+      for (int j = 0; j < 9; j++) s += H[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * x[j];
+      out9[9 * (int64_t)c + i] = (s + v) + lam * x[i];
     } else {
       out9[9 * (int64_t)c + threadIdx.x] = v;
     }
@@ -819,88 +835,122 @@ __global__ __launch_bounds__(BLK) void k_pcg_factor(int64_t ncams, double lambda
   if (bad) *flag = 1;
 }
 
-// z_c = (L L')^-1 r_c
-__global__ __launch_bounds__(BLK) void k_pcg_apply(int64_t ncams, const double *__restrict__ L45, const double *__restrict__ r,
-                                                    double *__restrict__ z) {
-  const int64_t c = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  if (c >= ncams) return;
-  double L[9][9], y[9];
-  int idx = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++)
-#pragma unroll
-    for (int j = 0; j <= i; j++) L[i][j] = L45[45 * c + idx++];
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-    double t = r[9 * c + i];
-#pragma unroll
-    for (int k = 0; k < i; k++) t -= L[i][k] * y[k];
-    y[i] = t / L[i][i];
-  }
-#pragma unroll
-  for (int i = 8; i >= 0; i--) {
-    double t = y[i];
-#pragma unroll
-    for (int k = i + 1; k < 9; k++) t -= L[k][i] * y[k];
-    y[i] = t / L[i][i];
-  }
-#pragma unroll
-  for (int i = 0; i < 9; i++) z[9 * c + i] = y[i];
-}
-
-// q_c = Hcc_c v_c + t_c   (Hcc packed lower; t = sum_a B_a' A_a h with h = -U^-1 W' v, see above); one lane per camera
-__global__ __launch_bounds__(BLK) void k_hcc_mv(int64_t ncams, const double *__restrict__ Hcc, const double *__restrict__ v,
-                                                 const double *__restrict__ t, double *__restrict__ q) {
-  const int64_t c = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  if (c >= ncams) return;
-  double H[9][9], x[9];
-  int idx = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++)
-#pragma unroll
-    for (int j = 0; j <= i; j++) {
-      H[i][j] = Hcc[45 * c + idx++];
-      H[j][i] = H[i][j];
-    }
-#pragma unroll
-  for (int i = 0; i < 9; i++) x[i] = v[9 * c + i];
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-    double s = 0;
-#pragma unroll
-    for (int j = 0; j < 9; j++) s += H[i][j] * x[j];
-    q[9 * c + i] = s + t[9 * c + i];
-  }
-}
-
-__global__ __launch_bounds__(BLK) void k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
-                                              double *__restrict__ partial) {
-  __shared__ double red[BLK / 64];
-  double acc = 0;
-  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) acc += a[i] * b[i];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-}
 // y += a x
 __global__ __launch_bounds__(BLK) void k_axpy_s(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y) {
   const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
   if (i < n) y[i] += a * x[i];
 }
-// x += alpha p, r -= alpha q
-__global__ __launch_bounds__(BLK) void k_cg_update(int64_t n, double alpha, const double *__restrict__ pd, const double *__restrict__ q,
-                                                    double *__restrict__ x, double *__restrict__ r) {
-  const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  if (i < n) {
-    x[i] += alpha * pd[i];
-    r[i] -= alpha * q[i];
+
+// The scalars of the CG iteration live on the device (cg[0] = p.q, cg[1] = r.r, cg[2] = r.z, cg[3] = alpha, cg[4] = beta):
+// the vector kernels read alpha / beta from there and the host looks at them once per iteration, for the stopping test only.
+// Reductions by ONE workgroup of 1024 lanes with a fixed tree (n = 9 ncams <= 1.3e5): deterministic and one launch.
+__device__ inline double block1024_sum(double v, double *red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0;
+  if (threadIdx.x < 16) t = red[threadIdx.x];
+  t += __shfl_xor(t, 1, 64);
+  t += __shfl_xor(t, 2, 64);
+  t += __shfl_xor(t, 4, 64);
+  t += __shfl_xor(t, 8, 64);
+  __syncthreads();
+  return t;  // valid in lane 0 of wave 0
+}
+// alpha = r.z / p.q (0 when p.q is not positive: the host stops there)
+__global__ __launch_bounds__(1024) void k_cg_alpha(int64_t n, const double *__restrict__ pd, const double *__restrict__ q,
+                                                    double *__restrict__ cg) {
+  __shared__ double red[16];
+  double acc = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += pd[i] * q[i];
+  const double pq = block1024_sum(acc, red);
+  if (threadIdx.x == 0) {
+    cg[0] = pq;
+    cg[3] = pq > 0 ? cg[2] / pq : 0.0;
   }
 }
-// p = z + beta p
-__global__ __launch_bounds__(BLK) void k_cg_dir(int64_t n, double beta, const double *__restrict__ z, double *__restrict__ pd) {
-  const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
-  if (i < n) pd[i] = z[i] + beta * pd[i];
+// x += alpha p, r -= alpha q, z = (L L')^-1 r per camera; per-block partial sums of r.r and r.z (one lane per camera).
+// first != 0: the start of the solve (x = 0, r = rhs are given): only z and the partial sums.
+__global__ __launch_bounds__(BLK) void k_cg_step(int64_t ncams, const double *__restrict__ cg, const double *__restrict__ L45,
+                                                  const double *__restrict__ pd, const double *__restrict__ q, double *__restrict__ x,
+                                                  double *__restrict__ r, double *__restrict__ z, double *__restrict__ partial,
+                                                  int first) {
+  __shared__ double red[2][BLK / 64];
+  const int64_t c = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  double rr = 0, rz = 0;
+  if (c < ncams) {
+    const double alpha = first ? 0.0 : cg[3];
+    double L[9][9], y[9], rc[9];
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) L[i][j] = L45[45 * c + idx++];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      if (first) {
+        rc[i] = r[9 * c + i];
+      } else {
+        x[9 * c + i] += alpha * pd[9 * c + i];
+        rc[i] = r[9 * c + i] - alpha * q[9 * c + i];
+        r[9 * c + i] = rc[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      double t = rc[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) t -= L[i][k] * y[k];
+      y[i] = t / L[i][i];
+    }
+#pragma unroll
+    for (int i = 8; i >= 0; i--) {
+      double t = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 9; k++) t -= L[k][i] * y[k];
+      y[i] = t / L[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      z[9 * c + i] = y[i];
+      rr += rc[i] * rc[i];
+      rz += rc[i] * y[i];
+    }
+  }
+  rr = wave_sum(rr);
+  rz = wave_sum(rz);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = rr;
+    red[1][threadIdx.x >> 6] = rz;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    partial[2 * blockIdx.x + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+  }
+}
+// r.r, r.z from the partials; beta = r.z / (previous r.z); p = z + beta p (first: p = z).  One workgroup.
+__global__ __launch_bounds__(1024) void k_cg_beta_dir(int64_t n, int nb, const double *__restrict__ partial, double *__restrict__ cg,
+                                                       const double *__restrict__ z, double *__restrict__ pd, int first) {
+  __shared__ double red[16];
+  __shared__ double sbeta;
+  double a0 = 0, a1 = 0;
+  for (int i = threadIdx.x; i < nb; i += 1024) {
+    a0 += partial[2 * i];
+    a1 += partial[2 * i + 1];
+  }
+  const double rr = block1024_sum(a0, red);
+  const double rz = block1024_sum(a1, red);
+  if (threadIdx.x == 0) {
+    const double beta = first ? 0.0 : rz / cg[2];
+    cg[1] = rr;
+    cg[2] = rz;
+    cg[4] = beta;
+    sbeta = beta;
+  }
+  __syncthreads();
+  const double beta = sbeta;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) pd[i] = first ? z[i] : z[i] + beta * pd[i];
 }
 
 }  // namespace
@@ -1113,16 +1163,17 @@ int launch_f16_scale(ba_problem *p, double lambda, double mu, const double *d_jn
 }
 
 // ---- PCG launchers ------------------------------------------------------------------------------------------------------
-// t_c = sum_a B_a' A_a h_p(a)
-int launch_wuw(ba_problem *p, const double *d_J, const double *d_h, double *d_t, hipStream_t st) {
+// q_c = Hcc_c v_c + lam v_c + sum_a B_a' A_a h_p(a)   (the camera sweep of the PCG product)
+int launch_wuw(ba_problem *p, const double *d_J, const double *d_h, const double *d_Hcc, const double *d_v, double lam, double *d_q,
+               hipStream_t st) {
   if (p->ncams == 0) return BA_OK;
   ProfScope ps(p, PC_SCHUR_RHS, st);
   if (staged_on())
     hipLaunchKernelGGL(k_cam_blocks_st<3>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
-                       (const double *)nullptr, d_h, (double *)nullptr, d_t);
+                       d_v, d_h, const_cast<double *>(d_Hcc), d_q, lam);
   else
     hipLaunchKernelGGL(k_cam_blocks<3>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
-                       (const double *)nullptr, d_h, (double *)nullptr, d_t);
+                       d_v, d_h, const_cast<double *>(d_Hcc), d_q, lam);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
@@ -1139,40 +1190,28 @@ int launch_pcg_factor(ba_problem *p, double lambda, double *d_blk45, int *d_flag
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
-int launch_pcg_apply(ba_problem *p, const double *d_L45, const double *d_r, double *d_z, hipStream_t st) {
-  hipLaunchKernelGGL(k_pcg_apply, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_L45, d_r, d_z);
-  BA_HIP_CHECK(hipGetLastError());
-  return BA_OK;
-}
-int launch_hcc_mv(ba_problem *p, const double *d_Hcc, const double *d_v, const double *d_t, double *d_q, hipStream_t st) {
-  hipLaunchKernelGGL(k_hcc_mv, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_Hcc, d_v, d_t, d_q);
-  BA_HIP_CHECK(hipGetLastError());
-  return BA_OK;
-}
-int launch_dot(ba_problem *p, int64_t n, const double *d_a, const double *d_b, double *d_partial, double *d_scal, int slot,
-               hipStream_t st) {
-  ProfScope ps(p, PC_REDUCE, st);
-  int nb = (int)((n + BLK - 1) / BLK);
-  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_dot, dim3(nb), dim3(BLK), 0, st, n, d_a, d_b, d_partial);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLK), 0, st, nb, d_partial, d_scal, slot);
-  BA_HIP_CHECK(hipGetLastError());
-  return BA_OK;
-}
 int launch_axpy_s(ba_problem *p, int64_t n, double a, const double *d_x, double *d_y, hipStream_t st) {
   if (n == 0) return BA_OK;
   hipLaunchKernelGGL(k_axpy_s, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, a, d_x, d_y);
   return BA_OK;
 }
-int launch_cg_update(ba_problem *p, int64_t n, double alpha, const double *d_p, const double *d_q, double *d_x, double *d_r,
-                     hipStream_t st) {
-  if (n == 0) return BA_OK;
-  hipLaunchKernelGGL(k_cg_update, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, alpha, d_p, d_q, d_x, d_r);
+int launch_cg_alpha(ba_problem *p, int64_t n, const double *d_p, const double *d_q, double *d_cg, hipStream_t st) {
+  ProfScope ps(p, PC_REDUCE, st);
+  hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(1024), 0, st, n, d_p, d_q, d_cg);
   return BA_OK;
 }
-int launch_cg_dir(ba_problem *p, int64_t n, double beta, const double *d_z, double *d_p, hipStream_t st) {
-  if (n == 0) return BA_OK;
-  hipLaunchKernelGGL(k_cg_dir, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, beta, d_z, d_p);
+// d_partial: 2 entries per block of 256 cameras
+int launch_cg_step(ba_problem *p, const double *d_cg, const double *d_L45, const double *d_p, const double *d_q, double *d_x,
+                   double *d_r, double *d_z, double *d_partial, int first, hipStream_t st) {
+  if (p->ncams == 0) return BA_OK;
+  hipLaunchKernelGGL(k_cg_step, dim3(grid_for(p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_cg, d_L45, d_p, d_q, d_x, d_r, d_z,
+                     d_partial, first);
+  return BA_OK;
+}
+int launch_cg_beta_dir(ba_problem *p, int64_t n, const double *d_partial, double *d_cg, const double *d_z, double *d_p, int first,
+                       hipStream_t st) {
+  ProfScope ps(p, PC_REDUCE, st);
+  hipLaunchKernelGGL(k_cg_beta_dir, dim3(1), dim3(1024), 0, st, n, (int)grid_for(p->ncams, BLK), d_partial, d_cg, d_z, d_p, first);
+  BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
