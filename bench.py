@@ -64,6 +64,10 @@ def parse():
                          "(--pcg-tol: its relative residual)")
     ap.add_argument("--pcg-tol", type=float, default=1e-8)
     ap.add_argument("--no-pcg", action="store_true", help="skip the secondary facto = :PCG measurement")
+    ap.add_argument("--emulate-shard", default=None, metavar="R/W",
+                    help="timing rehearsal on one GPU: run shard R of W of the workload (that rank's observations and points, all "
+                         "cameras) WITHOUT a communicator -- what one rank of a W-GPU job computes per iteration; the numbers "
+                         "are a rank's compute time, the results are not a solution of the full problem")
     ap.add_argument("--backend", default=os.environ.get("BA_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend: nccl (= RCCL, default) or gloo (host-staged all-reduce; rehearsal only)")
     ap.add_argument("--single-device", action="store_true",
@@ -131,6 +135,9 @@ def main():
     arrays = ba.synthetic.as_arrays(prob)
     if world > 1:
         arrays, info = ba.parallel.shard_problem(arrays, rank, world)
+    elif args.emulate_shard:
+        er, ew = (int(v) for v in args.emulate_shard.split("/"))
+        arrays, info = ba.parallel.shard_problem(arrays, er, ew)
     nlp = ba.BALNLPModel(arrays=arrays, device=local_rank, model_name=args.workload)
     fr = ba.FeasibilityResidual(nlp)
     reducer = ba.parallel.CameraBlockReducer(nlp) if world > 1 else None
@@ -341,7 +348,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload} shape: ncams={ncams} npnts={npnts_g} nobs={nobs_g}, seed "
                                    f"{ba.synthetic.BASE_SEED}, lm.jl variant, {FACTO}/None" + (f" (pcg_tol {PCG_TOL:g})" if FACTO == "PCG" else "") + f", facto_type {args.facto_type}, fixed {args.steps} iterations"
-                                   + ("" if args.scale == 1.0 else f" SCALED x{args.scale} (debug)"),
+                                   + ("" if args.scale == 1.0 else f" SCALED x{args.scale} (debug)")
+                                   + (f" EMULATED SHARD {args.emulate_shard} (one rank's compute, no communicator)" if args.emulate_shard else ""),
                        "parallelism": f"points sharded over {world} rank(s), cameras replicated"
                                       + ("" if world == 1 else "; reduced camera matrix reduced onto the owners of its tile column "
                                          "pairs, factorisation distributed (panel broadcast), solves replicated")},
