@@ -799,3 +799,25 @@ def test_lm_pcg_run_reaches_the_direct_minimum(ba, small_prob, gpu_ok):
     with pytest.raises(Exception):
         ba.Levenberg_Marquardt(fr, "PCG", "AMD", "None", False, facto_type=np.float16)
     m.close()
+
+
+@pytest.mark.parametrize("linesearch", [False, True])
+def test_lm_pcg_follows_the_oracle_through_rejections(ba, orc, small_prob, gpu_ok, linesearch):
+    """The hard start of the rejection tests, facto = :PCG solved tightly: rejected steps, the lambda updates of lm.jl:308,
+    329-337 and (with the line search, where :PCG re-evaluates the model value as :QR does, lm.jl:273) the rescaled steps
+    follow the ORACLE's :QR / :LDL run row by row over the well-conditioned prefix."""
+    p = small_prob
+    x0 = _hard_start(p)
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    kw = dict(nu_d=9.0, delta_d=2.0, ite_max=40, **_TIGHT)
+    st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "PCG", "AMD", "None", linesearch, x=x0, pcg_tol=1e-13,
+                                pcg_max_iter=5000, **kw)
+    rc, x_ref, st_ref, log_ref = orc.lm_solve(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], x0,
+                                              variant=1, linesearch=linesearch, facto="QR" if linesearch else "LDL", **kw)
+    assert rc == 0
+    n = _well_conditioned_prefix(log_ref)
+    print(f"oracle {st_ref.iter} rows, prefix {n}: {''.join('a' if v else 'r' for v in log_ref[:n, 7])}; device {st.iter} rows, "
+          f"{st.n_cg} CG iterations")
+    assert n >= 3 and (linesearch or [bool(v) for v in log_ref[:n, 7]].count(False) >= 1)
+    _compare_rows(st, log_ref, n)
+    m.close()
