@@ -284,6 +284,8 @@ static int lm_ensure(ba_problem *p) {
   BA_CHECK(dmalloc(&w->Hcc, 45 * ncams));
   BA_CHECK(dmalloc(&w->colscale, 9 * ncams));
   BA_CHECK(dmalloc(&w->partial, std::max<int64_t>(RED_BLOCKS, (npnts + 255) / 256)));  // k_backsub_st: one partial per 256 points
+  BA_HIP_CHECK(hipMalloc((void **)&w->cam_pnt, (size_t)(p->nobs > 0 ? p->nobs : 1) * sizeof(int)));
+  BA_CHECK(launch_cam_pnt(p, w->cam_pnt, p->stream));
   BA_CHECK(dmalloc(&w->s.scal_rep, (int64_t)RP_COUNT));
   BA_HIP_CHECK(hipHostMalloc((void **)&w->s.h_sh, SH_COUNT * sizeof(double)));
   BA_HIP_CHECK(hipHostMalloc((void **)&w->s.h_rp, RP_COUNT * sizeof(double)));
@@ -318,6 +320,7 @@ void lm_free(ba_problem *p) {
   for (double *q : {w->cgx, w->cgr, w->cgz, w->cgp, w->cgq, w->cgt, w->cgh, w->zero3, w->blk45, w->cg_scal})
     if (q) (void)hipFree(q);
   if (w->h_cg) (void)hipHostFree(w->h_cg);
+  if (w->cam_pnt) (void)hipFree(w->cam_pnt);
   if (w->d_lambda) (void)hipFree(w->d_lambda);
   if (w->h_lambda) (void)hipHostFree(w->h_lambda);
   if (w->h_flag) (void)hipHostFree(w->h_flag);
@@ -426,8 +429,10 @@ static int ensure_pcg(ba_problem *p, LMWorkFull *w) {
 // partial products are summed by one all-reduce and every rank adds the damping to the full sum
 static int pcg_matvec(ba_problem *p, LMWorkFull *w, double lambda, const double *v, double *q, hipStream_t st) {
   const bool shared = p->comm.active();
-  BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->zero3, v, w->cgh, st));  // h = -U^-1 W' v
-  BA_CHECK(launch_wuw(p, w->J, w->cgh, w->Hcc, v, shared ? 0.0 : lambda, q, st));
+  static const bool wtv_off = [] { const char *e = getenv("BA_PCG_WTV"); return e && e[0] == '0'; }();
+  if (p->point_sorted && !wtv_off) BA_CHECK(launch_wtv(p, w->J, w->Uinv, v, w->cgh, st));                 // h = -U^-1 W' v
+  else BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->zero3, v, w->cgh, st));  // (observations not grouped by point)
+  BA_CHECK(launch_wuw(p, w->J, w->cgh, w->Hcc, v, shared ? 0.0 : lambda, q, st, w->cam_pnt));
   if (!shared) return BA_OK;
   BA_CHECK(comm_allreduce(p, q, w->n, st));
   return launch_axpy_s(p, w->n, lambda, v, q, st);
@@ -496,7 +501,7 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, d_lambda, damp));
   if (w->pcg) {  // the reduced camera system is applied, not formed (pcg_solve); no column scaling: block Jacobi has its own
     BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
-    BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st));
+    BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
     BA_CHECK(comm_sum(p, w, w->s.off_rhs, w->npad, st));
     w->last_f32 = false;
     BA_CHECK(pcg_solve(p, w, lambda, st));
@@ -507,7 +512,7 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   BA_CHECK(launch_schur_blocks(p, &w->tasks, Jl, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
                                p->rank == 0 ? w->npad : w->n, st, d_lambda, damp));
   BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
-  BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st));
+  BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
   const bool dist = dist_factor_on(p);
   const bool reduce32 = dist && facto_f32 && normalize == 0;
   if (reduce32) BA_CHECK(ensure_f32(w));

@@ -39,6 +39,7 @@ struct LMWork {
   // facto_type = Float16: |J_j|^2, column norms, damping vector (nvar each), quantised J (24/obs) and r; allocated on first use
   double *jn2 = nullptr, *dcol = nullptr, *damp = nullptr, *Jq = nullptr, *rq = nullptr;
   double *partial = nullptr;             // RED_BLOCKS
+  int *cam_pnt = nullptr;                // nobs: the point of every observation in camera order (pnt0[cam_obs[q]])
   double *scal = nullptr;                // SC_COUNT device scalars
   double *h_scal = nullptr;              // pinned host mirror
   SchurTasks tasks;
@@ -56,7 +57,7 @@ int launch_col_sq(ba_problem *p, const double *d_Hpp, const double *d_hdiag, dou
 int launch_f16_scale(ba_problem *p, double lambda, double mu, const double *d_jn2, const double *d_J, const double *d_r,
                      double *d_dcol, double *d_damp, double *d_Jq, double *d_rq, hipStream_t st);
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
-                     hipStream_t st);
+                     hipStream_t st, const int *d_cam_pnt = nullptr);
 int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,
                    double *d_dp, hipStream_t st, const double *d_r_model = nullptr, double cr = 1.0, double *d_partial = nullptr,
                    double *d_scal = nullptr, int slot = 0, bool *model_done = nullptr);
@@ -75,7 +76,8 @@ int launch_scale_vec(ba_problem *p, int64_t n, const double *d_s, double *d_v, i
 
 // preconditioned conjugate gradients on the reduced camera system (facto = PCG; ba_normal_kernels.hip)
 int launch_wuw(ba_problem *p, const double *d_J, const double *d_h, const double *d_Hcc, const double *d_v, double lam, double *d_q,
-               hipStream_t st);
+               hipStream_t st, const int *d_cam_pnt = nullptr);
+int launch_cam_pnt(ba_problem *p, int *d_cam_pnt, hipStream_t st);
 int launch_schur_diag(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_Hcc, double *d_blk45, hipStream_t st);
 int launch_pcg_factor(ba_problem *p, double lambda, double *d_blk45, int *d_flag, hipStream_t st);
 int launch_axpy_s(ba_problem *p, int64_t n, double a, const double *d_x, double *d_y, hipStream_t st);
@@ -84,3 +86,4 @@ int launch_cg_step(ba_problem *p, const double *d_cg, const double *d_L45, const
                    double *d_r, double *d_z, double *d_partial, int first, hipStream_t st);
 int launch_cg_beta_dir(ba_problem *p, int64_t n, const double *d_partial, double *d_cg, const double *d_z, double *d_p, int first,
                        hipStream_t st);
+int launch_wtv(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_v, double *d_h, hipStream_t st);

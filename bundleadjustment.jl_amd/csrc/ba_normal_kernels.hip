@@ -153,10 +153,10 @@ __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ inline void stage_rows(const double *__restrict__ J, const int *__restrict__ rows, int64_t q0, int nrows,
-                                  double *slot) {
+// the two halves of stage_rows: the 12 requests of a batch (in registers until they are committed), and their way into the
+// wave's LDS slot.  Issued one batch ahead they overlap the work on the current batch (k_wtv).
+__device__ inline void stage_issue(const double *__restrict__ J, const int *__restrict__ rows, int64_t q0, int nrows, d2n v[12]) {
   const int lane = threadIdx.x & 63;
-  d2n v[12];
 #pragma unroll
   for (int ps = 0; ps < 12; ps++) {  // piece f = 64 ps + lane of the 768 16-byte pieces: row f / 12, piece f % 12
     const int f = ps * 64 + lane;
@@ -166,6 +166,9 @@ __device__ inline void stage_rows(const double *__restrict__ J, const int *__res
     const int64_t o = rows ? (int64_t)rows[q0 + r] : q0 + r;
     v[ps] = *reinterpret_cast<const d2n *>(J + 24 * o + 2 * pc);
   }
+}
+__device__ inline void stage_commit(const d2n v[12], double *slot) {
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int ps = 0; ps < 12; ps++) {
     const int f = ps * 64 + lane;
@@ -175,6 +178,12 @@ __device__ inline void stage_rows(const double *__restrict__ J, const int *__res
   }
   wave_lds_sync();
 }
+__device__ inline void stage_rows(const double *__restrict__ J, const int *__restrict__ rows, int64_t q0, int nrows,
+                                  double *slot) {
+  d2n v[12];
+  stage_issue(J, rows, q0, nrows, v);
+  stage_commit(v, slot);
+}
 
 // camera side with staged rows: same work item, same summation order as k_cam_blocks (thread t of camera c takes list
 // positions t, t + 256, ...), hence the same bits
@@ -182,7 +191,8 @@ template <int MODE>
 __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ cam_ptr, const int *__restrict__ cam_obs,
                                                         const int *__restrict__ pnt0, const double *__restrict__ J,
                                                         const double *__restrict__ r, const double *__restrict__ u,
-                                                        double *__restrict__ Hcc, double *__restrict__ out9, double lam = 0.0) {
+                                                        double *__restrict__ Hcc, double *__restrict__ out9, double lam = 0.0,
+                                                        const int *__restrict__ cam_pnt = nullptr) {
   constexpr int NACC = (MODE == 0) ? 54 : 9;
   __shared__ double slots[(BLK / 64) * ST_WAVE_ELEMS];
   __shared__ double red[BLK / 64][NACC];
@@ -195,6 +205,17 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ c
   const int qend = cam_ptr[c + 1];
   for (int q0 = cam_ptr[c] + wv * 64; q0 < qend; q0 += BLK) {  // wave-uniform
     const int nrows = qend - q0 < 64 ? qend - q0 : 64;
+    // MODE 2 / 3: the point-side vector of this lane's observation is requested BEFORE the rows are staged, so that the
+    // chain index -> point index -> u overlaps the chain index -> row instead of following it (cam_pnt = the point index in
+    // camera order, one indirection less): 117.9 -> 107.3 ms over the 288 products of a Venice PCG run.  (Requesting the
+    // rows themselves one batch ahead, as k_wtv does, made this kernel slower: 124 ms.)
+    double up3[3] = {0, 0, 0};
+    if ((MODE == 2 || MODE == 3) && lane < nrows) {
+      const int64_t pi = cam_pnt ? cam_pnt[q0 + lane] : pnt0[cam_obs[q0 + lane]];
+      up3[0] = u[3 * pi];
+      up3[1] = u[3 * pi + 1];
+      up3[2] = u[3 * pi + 2];
+    }
     stage_rows(J, cam_obs, q0, nrows, slot);
     if (lane < nrows) {
       const int64_t o = cam_obs[q0 + lane];
@@ -207,11 +228,11 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ c
       }
       double w0, w1;
       if (MODE == 2) {
-        const double *up = u + 3 * (int64_t)pnt0[o];
+        const double *up = up3;
         w0 = (Jo[0] * up[0] + Jo[1] * up[1] + Jo[2] * up[2]) - r[2 * o];
         w1 = (Jo[12] * up[0] + Jo[13] * up[1] + Jo[14] * up[2]) - r[2 * o + 1];
       } else if (MODE == 3) {
-        const double *up = u + 3 * (int64_t)pnt0[o];
+        const double *up = up3;
         w0 = Jo[0] * up[0] + Jo[1] * up[1] + Jo[2] * up[2];
         w1 = Jo[12] * up[0] + Jo[13] * up[1] + Jo[14] * up[2];
       } else {
@@ -835,6 +856,71 @@ __global__ __launch_bounds__(BLK) void k_pcg_factor(int64_t ncams, double lambda
   if (bad) *flag = 1;
 }
 
+// The point sweep of the PCG product, h_p = -U_p^-1 sum_a A_a' (B_a v[cam(a)]): like k_backsub_st a wave owns 64 consecutive
+// points and walks their (contiguous) observations in batches of 64 staged rows, but the per-observation part -- B_a v, then
+// A_a' of it -- is done with ONE LANE PER OBSERVATION of the batch; the lanes then switch to their points and add up the
+// 3-vectors of their own observations from LDS.  (In k_backsub_st a lane does all of that for its point's observations one
+// after the other while the lanes of the other ~50 points of the wave have no observation in the batch.)
+__global__ __launch_bounds__(BLK) void k_wtv(int64_t npnts, const int *__restrict__ pt_ptr, const int *__restrict__ cam0,
+                                              const double *__restrict__ J, const double *__restrict__ Uinv,
+                                              const double *__restrict__ v, double *__restrict__ h) {
+  __shared__ double slots[(BLK / 64) * ST_WAVE_ELEMS];
+  __shared__ double wb[(BLK / 64) * 64 * 3];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t p0 = (int64_t)blockIdx.x * BLK + wv * 64;
+  if (p0 >= npnts) return;  // wave-uniform; no workgroup barrier below
+  double *slot = slots + wv * ST_WAVE_ELEMS, *wbuf = wb + wv * 64 * 3;
+  const int64_t p = p0 + lane, plast = p0 + 64 < npnts ? p0 + 64 : npnts;
+  const int qb = pt_ptr[p0], qe = pt_ptr[plast];
+  const int mb = p < npnts ? pt_ptr[p] : qe, me = p < npnts ? pt_ptr[p + 1] : qe;
+  double t[3] = {0, 0, 0};
+  d2n pv[12];
+  int cn = 0;
+  auto issue = [&](int q0) {  // the rows and camera indices of the next batch, requested before the current one is worked on
+    const int nrows = qe - q0 < 64 ? qe - q0 : 64;
+    cn = cam0[q0 + (lane < nrows ? lane : nrows - 1)];
+    stage_issue(J, nullptr, q0, nrows, pv);
+  };
+  if (qb < qe) issue(qb);
+  for (int q0 = qb; q0 < qe; q0 += 64) {
+    const int nrows = qe - q0 < 64 ? qe - q0 : 64;
+    const int ci = cn;
+    stage_commit(pv, slot);
+    if (q0 + 64 < qe) issue(q0 + 64);
+    if (lane < nrows) {
+      const double *Jo = slot + lane * JLD;
+      const double *d = v + 9 * (int64_t)ci;
+      double s0 = 0, s1 = 0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        s0 += Jo[3 + i] * d[i];
+        s1 += Jo[15 + i] * d[i];
+      }
+      wbuf[3 * lane + 0] = Jo[0] * s0 + Jo[12] * s1;
+      wbuf[3 * lane + 1] = Jo[1] * s0 + Jo[13] * s1;
+      wbuf[3 * lane + 2] = Jo[2] * s0 + Jo[14] * s1;
+    }
+    wave_lds_sync();
+    const int lo = mb > q0 ? mb : q0, hi = me < q0 + 64 ? me : q0 + 64;
+    for (int q = lo; q < hi; q++) {
+      t[0] += wbuf[3 * (q - q0) + 0];
+      t[1] += wbuf[3 * (q - q0) + 1];
+      t[2] += wbuf[3 * (q - q0) + 2];
+    }
+    wave_lds_sync();  // slot and wbuf are rewritten by the next batch
+  }
+  if (p < npnts) {
+    const double *U = Uinv + 6 * p;
+    h[3 * p + 0] = -((U[0] * t[0] + U[1] * t[1]) + U[2] * t[2]);
+    h[3 * p + 1] = -((U[1] * t[0] + U[3] * t[1]) + U[4] * t[2]);
+    h[3 * p + 2] = -((U[2] * t[0] + U[4] * t[1]) + U[5] * t[2]);
+  }
+}
+
+__global__ __launch_bounds__(BLK) void k_gather_int(int64_t n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
 // y += a x
 __global__ __launch_bounds__(BLK) void k_axpy_s(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y) {
   const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
@@ -1056,12 +1142,12 @@ int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, do
 }
 
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
-                     hipStream_t st) {
+                     hipStream_t st, const int *d_cam_pnt) {
   if (p->ncams == 0) return BA_OK;
   ProfScope ps(p, PC_SCHUR_RHS, st);
   if (staged_on())
     hipLaunchKernelGGL(k_cam_blocks_st<2>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
-                       d_r, d_u, (double *)nullptr, d_rhs);
+                       d_r, d_u, (double *)nullptr, d_rhs, 0.0, d_cam_pnt);
   else
     hipLaunchKernelGGL(k_cam_blocks<2>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
                        d_r, d_u, (double *)nullptr, d_rhs);
@@ -1165,12 +1251,12 @@ int launch_f16_scale(ba_problem *p, double lambda, double mu, const double *d_jn
 // ---- PCG launchers ------------------------------------------------------------------------------------------------------
 // q_c = Hcc_c v_c + lam v_c + sum_a B_a' A_a h_p(a)   (the camera sweep of the PCG product)
 int launch_wuw(ba_problem *p, const double *d_J, const double *d_h, const double *d_Hcc, const double *d_v, double lam, double *d_q,
-               hipStream_t st) {
+               hipStream_t st, const int *d_cam_pnt) {
   if (p->ncams == 0) return BA_OK;
   ProfScope ps(p, PC_SCHUR_RHS, st);
   if (staged_on())
     hipLaunchKernelGGL(k_cam_blocks_st<3>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
-                       d_v, d_h, const_cast<double *>(d_Hcc), d_q, lam);
+                       d_v, d_h, const_cast<double *>(d_Hcc), d_q, lam, d_cam_pnt);
   else
     hipLaunchKernelGGL(k_cam_blocks<3>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
                        d_v, d_h, const_cast<double *>(d_Hcc), d_q, lam);
@@ -1212,6 +1298,21 @@ int launch_cg_beta_dir(ba_problem *p, int64_t n, const double *d_partial, double
                        hipStream_t st) {
   ProfScope ps(p, PC_REDUCE, st);
   hipLaunchKernelGGL(k_cg_beta_dir, dim3(1), dim3(1024), 0, st, n, (int)grid_for(p->ncams, BLK), d_partial, d_cg, d_z, d_p, first);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+// h = -U^-1 W' v (the point sweep of the PCG product); observations grouped by point (BAL order)
+int launch_wtv(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_v, double *d_h, hipStream_t st) {
+  if (p->npnts == 0) return BA_OK;
+  ProfScope ps(p, PC_BACKSUB, st);
+  hipLaunchKernelGGL(k_wtv, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->cam0, d_J, d_Uinv, d_v, d_h);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+// cam_pnt[q] = pnt0[cam_obs[q]]: the point of every observation in camera order (built once per problem)
+int launch_cam_pnt(ba_problem *p, int *d_cam_pnt, hipStream_t st) {
+  if (p->nobs == 0) return BA_OK;
+  hipLaunchKernelGGL(k_gather_int, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->cam_obs, p->pnt0, d_cam_pnt);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
