@@ -429,8 +429,7 @@ static int ensure_pcg(ba_problem *p, LMWorkFull *w) {
 // partial products are summed by one all-reduce and every rank adds the damping to the full sum
 static int pcg_matvec(ba_problem *p, LMWorkFull *w, double lambda, const double *v, double *q, hipStream_t st) {
   const bool shared = p->comm.active();
-  static const bool wtv_off = [] { const char *e = getenv("BA_PCG_WTV"); return e && e[0] == '0'; }();
-  if (p->point_sorted && !wtv_off) BA_CHECK(launch_wtv(p, w->J, w->Uinv, v, w->cgh, st));                 // h = -U^-1 W' v
+  if (p->point_sorted) BA_CHECK(launch_wtv(p, w->J, w->Uinv, v, w->cgh, st));  // h = -U^-1 W' v
   else BA_CHECK(launch_backsub(p, w->J, w->Uinv, w->zero3, v, w->cgh, st));  // (observations not grouped by point)
   BA_CHECK(launch_wuw(p, w->J, w->cgh, w->Hcc, v, shared ? 0.0 : lambda, q, st, w->cam_pnt));
   if (!shared) return BA_OK;

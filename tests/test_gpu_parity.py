@@ -154,6 +154,9 @@ def test_unsorted_observations(ba, orc, small_prob, gpu_ok):
     rc, d_ref, dr_ref, _ = orc.lm_step(p["ncams"], p["npnts"], cam, pnt, pt2d, p["x0"], 10.0)
     assert rc == 0
     assert np.linalg.norm(d - d_ref) <= 1e-9 * np.linalg.norm(d_ref)
+    # facto = :PCG on unsorted observations: the product's point sweep falls back to the list-driven kernel
+    dp, _, _, its = ba.lm_step(m, p["x0"], 10.0, pcg=(1e-13, 5000))
+    assert 0 < its < 5000 and np.linalg.norm(dp - d_ref) <= 1e-8 * np.linalg.norm(d_ref)
     m.close()
 
 
