@@ -1283,7 +1283,7 @@ void dense_ldl_layout(int64_t nt, int world, std::vector<int64_t> *col_off, std:
 }
 
 template <typename T>
-int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world, int rank) {
+int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world, int rank, bool lazy_S) {
   int64_t nt = (n_unpadded + NB - 1) / NB;
   if (nt < 1) nt = 1;
   w->n = nt * NB;
@@ -1310,11 +1310,11 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
   if (external_S) {
     w->S = external_S;
     w->own_S = false;
-  } else {
+  } else if (!lazy_S) {
     BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)dense_ldl_tiles_doubles(n_unpadded) * sizeof(T)));
     w->own_S = true;
   }
-  BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(T)));  // 2 x two panels of L*D
+  if (!lazy_S) BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(T)));  // 2 x two panels of L*D
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_chain, hipEventDisableTiming | hipEventReleaseToDevice));
   BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(T)));
   // k_ldl_diag writes the lower triangle of each inverse only; the consumers read whole tiles
@@ -1329,6 +1329,16 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
     BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_upd[q], hipEventDisableTiming));
   }
   return set_kernel_attrs<T>();
+}
+
+template <typename T>
+int dense_ldl_alloc_S(DenseLDLT<T> *w) {
+  if (!w->S) {
+    BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)(w->nt * (w->nt + 1) / 2) * NB * NB * sizeof(T)));
+    w->own_S = true;
+  }
+  if (!w->V) BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * w->nt * NB * NB * sizeof(T)));
+  return BA_OK;
 }
 
 template <typename T>
@@ -1747,8 +1757,10 @@ extern "C" int ba_dense_ldl_solve_f32(int device, int64_t n, const double *a_low
   return dense_solve_host<float>(device, n, a_lower_rowmajor, b, x, factor_ms);
 }
 
-template int dense_ldl_alloc<double>(DenseLDLT<double> *, int64_t, double *, int, int);
-template int dense_ldl_alloc<float>(DenseLDLT<float> *, int64_t, float *, int, int);
+template int dense_ldl_alloc<double>(DenseLDLT<double> *, int64_t, double *, int, int, bool);
+template int dense_ldl_alloc<float>(DenseLDLT<float> *, int64_t, float *, int, int, bool);
+template int dense_ldl_alloc_S<double>(DenseLDLT<double> *);
+template int dense_ldl_alloc_S<float>(DenseLDLT<float> *);
 template void dense_ldl_free<double>(DenseLDLT<double> *);
 template void dense_ldl_free<float>(DenseLDLT<float> *);
 template int dense_ldl_factor<double>(ba_problem *, DenseLDLT<double> *, hipStream_t, int *, double *);

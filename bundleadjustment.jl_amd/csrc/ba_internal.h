@@ -169,7 +169,10 @@ int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, doubl
 
 // ---- dense LDL^T (ba_dense_ldl.hip) ---------------------------------------------------------------
 template <typename T>
-int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world = 1, int rank = 0);
+int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world = 1, int rank = 0, bool lazy_S = false);
+// lazy_S: the tiles of S (and the panel buffers V) are left out until dense_ldl_alloc_S
+template <typename T>
+int dense_ldl_alloc_S(DenseLDLT<T> *w);
 template <typename T>
 void dense_ldl_free(DenseLDLT<T> *w);
 int64_t dense_ldl_tiles_doubles(int64_t n_unpadded);  // number of ELEMENTS of the packed lower tiles

@@ -150,20 +150,19 @@ int build_tasks(ba_problem *p, SchurTasks *T) {
   return BA_OK;
 }
 
-// one device buffer [S tiles | rhs(npad) | gc(npad) | hdiag(npad) | SH_COUNT scalars]: gc, hdiag and the first scalars
-// are one all-reduce
+// one device buffer [rhs(npad) | gc(npad) | hdiag(npad) | SH_COUNT scalars]: gc, hdiag and the first scalars are one
+// all-reduce.  (The tiles of S are their own allocation, made when the first direct solve needs them: ensure_dense.)
 int64_t reduce_layout(ba_problem *p, int64_t *off_rhs, int64_t *off_gc, int64_t *off_scal) {
   const int64_t n = 9 * p->ncams;
-  const int64_t tiles = dense_ldl_tiles_doubles(n);
   const int64_t npad = ((n + NB - 1) / NB > 0 ? (n + NB - 1) / NB : 1) * NB;
-  if (off_rhs) *off_rhs = tiles;
-  if (off_gc) *off_gc = tiles + npad;
-  if (off_scal) *off_scal = tiles + 3 * npad;
-  return tiles + 3 * npad + SH_COUNT;
+  if (off_rhs) *off_rhs = 0;
+  if (off_gc) *off_gc = npad;
+  if (off_scal) *off_scal = 3 * npad;
+  return 3 * npad + SH_COUNT;
 }
 
 struct LMState {
-  double *red = nullptr;  // [S tiles | rhs | gc | sharded scalars]
+  double *red = nullptr;  // [rhs | gc | hdiag | sharded scalars]
   bool own_red = false;
   int64_t off_rhs = 0, off_gc = 0, off_scal = 0, red_doubles = 0;
   double *scal_rep = nullptr;
@@ -262,8 +261,11 @@ static int lm_ensure(ba_problem *p) {
   w->s.red_doubles = reduce_layout(p, &w->s.off_rhs, &w->s.off_gc, &w->s.off_scal);
   BA_CHECK(dmalloc(&w->s.red, w->s.red_doubles));
   w->s.own_red = true;
-  // with a communicator the tile column pairs of S are laid out by owner rank (one contiguous range per rank)
-  BA_CHECK(dense_ldl_alloc(&w->ldl, w->n, w->s.red, p->comm.active() ? p->comm.world : 1, p->comm.active() ? p->comm.rank : 0));
+  // with a communicator the tile column pairs of S are laid out by owner rank (one contiguous range per rank).  The tiles
+  // themselves (n^2/2 doubles: 1 GB for Venice, 60 GB for Final-13682), the Schur task list and the per-observation Y blocks
+  // are allocated by ensure_dense when a direct solve first needs them: a handle that only ever runs facto = :PCG never
+  // holds anything of the size of S.
+  BA_CHECK(dense_ldl_alloc(&w->ldl, w->n, (double *)nullptr, p->comm.active() ? p->comm.world : 1, p->comm.active() ? p->comm.rank : 0, true));
   w->npad = w->ldl.n;
   w->rhs = w->s.red + w->s.off_rhs;
   w->gc = w->s.red + w->s.off_gc;
@@ -280,7 +282,6 @@ static int lm_ensure(ba_problem *p) {
   BA_CHECK(dmalloc(&w->gp, 3 * npnts));
   BA_CHECK(dmalloc(&w->Uinv, 6 * npnts));
   BA_CHECK(dmalloc(&w->u, 3 * npnts));
-  BA_CHECK(dmalloc(&w->Yobs, 6 * nobs));
   BA_CHECK(dmalloc(&w->Hcc, 45 * ncams));
   BA_CHECK(dmalloc(&w->colscale, 9 * ncams));
   BA_CHECK(dmalloc(&w->partial, std::max<int64_t>(RED_BLOCKS, (npnts + 255) / 256)));  // k_backsub_st: one partial per 256 points
@@ -292,8 +293,15 @@ static int lm_ensure(ba_problem *p) {
   BA_HIP_CHECK(hipHostMalloc((void **)&w->h_lambda, sizeof(double)));
   BA_HIP_CHECK(hipHostMalloc((void **)&w->h_flag, sizeof(int)));
   BA_CHECK(dmalloc(&w->d_lambda, (int64_t)1));
-  BA_CHECK(build_tasks(p, &w->tasks));
   return BA_OK;
+}
+
+// what only the direct solves need: the tiles of S, the Schur task list, the per-observation Y blocks
+static int ensure_dense(ba_problem *p, LMWorkFull *w) {
+  if (w->ldl.S) return BA_OK;
+  BA_CHECK(dense_ldl_alloc_S(&w->ldl));
+  BA_CHECK(dmalloc(&w->Yobs, 6 * p->nobs));
+  return build_tasks(p, &w->tasks);
 }
 
 void lm_free(ba_problem *p) {
@@ -350,7 +358,10 @@ static bool dist_factor_on(ba_problem *p) {
 // Float32 ulps, the level of the factorisation itself.
 static int reduce_camera_system(ba_problem *p, LMWorkFull *w, hipStream_t st, bool s32 = false) {
   if (!p->comm.active()) return BA_OK;
-  if (!dist_factor_on(p)) return comm_sum(p, w, 0, w->s.off_gc, st);  // S tiles and rhs are adjacent
+  if (!dist_factor_on(p)) {  // replicated: the whole S and the right-hand side everywhere
+    BA_CHECK(comm_allreduce(p, w->ldl.S, dense_ldl_tiles_doubles(w->n), st));
+    return comm_sum(p, w, w->s.off_rhs, w->npad, st);
+  }
   if (s32) BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, dense_ldl_tiles_doubles(w->n), st));
   BA_CHECK(comm_group_begin(p));
   int rc = BA_OK;
@@ -716,6 +727,7 @@ static int lm_step_impl(ba_problem *p, const double *x, double lambda, double *d
   w->pcg_tol = tol > 0 ? tol : 1e-8;
   w->pcg_maxit = max_iter > 0 ? max_iter : 0;
   w->n_cg = 0;
+  if (!pcg) BA_CHECK(ensure_dense(p, w));
   BA_HIP_CHECK(hipMemcpyAsync(w->x, x, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
   w->f16 = false;
   BA_CHECK(refresh_linearisation(p, w, true, st));
@@ -802,6 +814,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   w->pcg_tol = o->pcg_tol > 0 ? o->pcg_tol : 1e-8;
   w->pcg_maxit = o->pcg_max_iter > 0 ? o->pcg_max_iter : 0;
   w->n_cg = 0;
+  if (!w->pcg) BA_CHECK(ensure_dense(p, w));  // (here, not in linear_step: no allocation while a graph is being recorded)
   const double eps = xf32 ? 1.1920928955078125e-07 : 2.220446049250313e-16, sq = std::sqrt(eps), cbr = std::pow(eps, 1.0 / 3.0);
   const double restol = o->restol >= 0 ? o->restol : (V ? cbr : 100 * sq);
   const double satol = o->satol >= 0 ? o->satol : sq, srtol = o->srtol >= 0 ? o->srtol : sq;
