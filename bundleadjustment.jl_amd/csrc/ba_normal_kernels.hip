@@ -184,6 +184,27 @@ __device__ inline void stage_rows(const double *__restrict__ J, const int *__res
   stage_issue(J, rows, q0, nrows, v);
   stage_commit(v, slot);
 }
+// the same with the 12 row numbers of a lane's pieces already at hand (stage_row_ids, requested one batch ahead: the chain
+// index -> row then costs one memory round trip per batch instead of two)
+__device__ inline void stage_row_ids(const int *__restrict__ rows, int64_t q0, int nrows, int ro[12]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int ps = 0; ps < 12; ps++) {
+    int r = (ps * 64 + lane) / 12;
+    r = r < nrows ? r : nrows - 1;
+    ro[ps] = rows[q0 + r];
+  }
+}
+__device__ inline void stage_rows_by_id(const double *__restrict__ J, const int ro[12], double *slot) {
+  const int lane = threadIdx.x & 63;
+  d2n v[12];
+#pragma unroll
+  for (int ps = 0; ps < 12; ps++) {
+    const int f = ps * 64 + lane, pc = f - 12 * (f / 12);
+    v[ps] = *reinterpret_cast<const d2n *>(J + 24 * (int64_t)ro[ps] + 2 * pc);
+  }
+  stage_commit(v, slot);
+}
 
 // camera side with staged rows: same work item, same summation order as k_cam_blocks (thread t of camera c takes list
 // positions t, t + 256, ...), hence the same bits
@@ -203,12 +224,17 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ c
 #pragma unroll
   for (int i = 0; i < NACC; i++) acc[i] = 0;
   const int qend = cam_ptr[c + 1];
+  int ro[12], ron[12];  // row numbers of this lane's pieces: current batch, next batch
+  if (cam_ptr[c] + wv * 64 < qend) {
+    const int q0 = cam_ptr[c] + wv * 64;
+    stage_row_ids(cam_obs, q0, qend - q0 < 64 ? qend - q0 : 64, ro);
+  }
   for (int q0 = cam_ptr[c] + wv * 64; q0 < qend; q0 += BLK) {  // wave-uniform
     const int nrows = qend - q0 < 64 ? qend - q0 : 64;
     // MODE 2 / 3: the point-side vector of this lane's observation is requested BEFORE the rows are staged, so that the
     // chain index -> point index -> u overlaps the chain index -> row instead of following it (cam_pnt = the point index in
     // camera order, one indirection less): 117.9 -> 107.3 ms over the 288 products of a Venice PCG run.  (Requesting the
-    // rows themselves one batch ahead, as k_wtv does, made this kernel slower: 124 ms.)
+    // rows themselves one batch ahead, as k_wtv does, made this kernel slower: 124 ms; the row NUMBERS are requested ahead.)
     double up3[3] = {0, 0, 0};
     if ((MODE == 2 || MODE == 3) && lane < nrows) {
       const int64_t pi = cam_pnt ? cam_pnt[q0 + lane] : pnt0[cam_obs[q0 + lane]];
@@ -216,7 +242,13 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ c
       up3[1] = u[3 * pi + 1];
       up3[2] = u[3 * pi + 2];
     }
-    stage_rows(J, cam_obs, q0, nrows, slot);
+    const bool more = q0 + BLK < qend;
+    if (more) stage_row_ids(cam_obs, q0 + BLK, qend - (q0 + BLK) < 64 ? qend - (q0 + BLK) : 64, ron);  // in flight behind the rows
+    stage_rows_by_id(J, ro, slot);
+    if (more) {
+#pragma unroll
+      for (int ps = 0; ps < 12; ps++) ro[ps] = ron[ps];
+    }
     if (lane < nrows) {
       const int64_t o = cam_obs[q0 + lane];
       const double *Jo = slot + lane * JLD;
