@@ -284,7 +284,7 @@ static int lm_ensure(ba_problem *p) {
   BA_CHECK(dmalloc(&w->u, 3 * npnts));
   BA_CHECK(dmalloc(&w->Hcc, 45 * ncams));
   BA_CHECK(dmalloc(&w->colscale, 9 * ncams));
-  BA_CHECK(dmalloc(&w->partial, std::max<int64_t>(RED_BLOCKS, (npnts + 255) / 256)));  // k_backsub_st: one partial per 256 points
+  BA_CHECK(dmalloc(&w->partial, std::max<int64_t>(RED_BLOCKS, (npnts + 255) / 256)));  // k_wtv<true>: one partial per 256 points
   BA_HIP_CHECK(hipMalloc((void **)&w->cam_pnt, (size_t)(p->nobs > 0 ? p->nobs : 1) * sizeof(int)));
   BA_CHECK(launch_cam_pnt(p, w->cam_pnt, p->stream));
   BA_CHECK(dmalloc(&w->s.scal_rep, (int64_t)RP_COUNT));

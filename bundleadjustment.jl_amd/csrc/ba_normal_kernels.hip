@@ -683,87 +683,6 @@ __global__ __launch_bounds__(BLK) void k_model_sq(int64_t nobs, int64_t npnts, c
   if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-// Back-substitution with staged rows (point-sorted observations), one lane per point as k_backsub, and -- because the rows
-// and dc are at hand -- the model value 1/2 |J delta + cr r|^2 of the step in the same pass over J (a second sweep over the
-// wave's row range, L2-warm): partial[blockIdx.x] = this block's part of sum |J delta + cr r|^2 (r == null: not wanted).
-__global__ __launch_bounds__(BLK) void k_backsub_st(int64_t npnts, const int *__restrict__ pt_ptr, const int *__restrict__ cam0,
-                                                     const double *__restrict__ J, const double *__restrict__ Uinv,
-                                                     const double *__restrict__ u, const double *__restrict__ dc,
-                                                     double *__restrict__ dp, const double *__restrict__ r, double cr,
-                                                     double *__restrict__ partial) {
-  __shared__ double slots[(BLK / 64) * ST_WAVE_ELEMS];
-  __shared__ double red[BLK / 64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t p0 = (int64_t)blockIdx.x * BLK + wv * 64;
-  double acc = 0;
-  if (p0 < npnts) {  // wave-uniform
-    double *slot = slots + wv * ST_WAVE_ELEMS;
-    const int64_t p = p0 + lane, plast = p0 + 64 < npnts ? p0 + 64 : npnts;
-    const int qb = pt_ptr[p0], qe = pt_ptr[plast];
-    const int mb = p < npnts ? pt_ptr[p] : qe, me = p < npnts ? pt_ptr[p + 1] : qe;
-    double w[3] = {0, 0, 0};
-    for (int q0 = qb; q0 < qe; q0 += 64) {
-      const int nrows = qe - q0 < 64 ? qe - q0 : 64;
-      stage_rows(J, nullptr, q0, nrows, slot);
-      const int lo = mb > q0 ? mb : q0, hi = me < q0 + 64 ? me : q0 + 64;
-      for (int q = lo; q < hi; q++) {
-        const double *Jo = slot + (q - q0) * JLD;
-        const double *d = dc + 9 * (int64_t)cam0[q];
-        double s0 = 0, s1 = 0;
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-          s0 += Jo[3 + i] * d[i];
-          s1 += Jo[15 + i] * d[i];
-        }
-        w[0] += Jo[0] * s0 + Jo[12] * s1;
-        w[1] += Jo[1] * s0 + Jo[13] * s1;
-        w[2] += Jo[2] * s0 + Jo[14] * s1;
-      }
-      wave_lds_sync();
-    }
-    double d3[3] = {0, 0, 0};
-    if (p < npnts) {
-      const double *U = Uinv + 6 * p;
-      d3[0] = -(u[3 * p + 0] + (U[0] * w[0] + U[1] * w[1] + U[2] * w[2]));
-      d3[1] = -(u[3 * p + 1] + (U[1] * w[0] + U[3] * w[1] + U[4] * w[2]));
-      d3[2] = -(u[3 * p + 2] + (U[2] * w[0] + U[4] * w[1] + U[5] * w[2]));
-      dp[3 * p + 0] = d3[0];
-      dp[3 * p + 1] = d3[1];
-      dp[3 * p + 2] = d3[2];
-    }
-    if (r) {
-      for (int q0 = qb; q0 < qe; q0 += 64) {
-        const int nrows = qe - q0 < 64 ? qe - q0 : 64;
-        stage_rows(J, nullptr, q0, nrows, slot);
-        const int lo = mb > q0 ? mb : q0, hi = me < q0 + 64 ? me : q0 + 64;
-        for (int q = lo; q < hi; q++) {
-          const double *Jo = slot + (q - q0) * JLD;
-          const double *d = dc + 9 * (int64_t)cam0[q];
-          double s0 = cr * r[2 * (int64_t)q], s1 = cr * r[2 * (int64_t)q + 1];
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            s0 += Jo[i] * d3[i];
-            s1 += Jo[12 + i] * d3[i];
-          }
-#pragma unroll
-          for (int i = 0; i < 9; i++) {
-            s0 += Jo[3 + i] * d[i];
-            s1 += Jo[15 + i] * d[i];
-          }
-          acc += s0 * s0 + s1 * s1;
-        }
-        wave_lds_sync();
-      }
-    }
-  }
-  if (r) {
-    acc = wave_sum(acc);
-    if (lane == 0) red[wv] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-  }
-}
-
 // sum of squares of a vector -> per-block partials (fixed grid => fixed summation tree)
 __global__ __launch_bounds__(BLK) void k_sumsq(int64_t n, const double *__restrict__ v, double *__restrict__ partial) {
   __shared__ double red[BLK / 64];
@@ -888,64 +807,127 @@ __global__ __launch_bounds__(BLK) void k_pcg_factor(int64_t ncams, double lambda
   if (bad) *flag = 1;
 }
 
-// The point sweep of the PCG product, h_p = -U_p^-1 sum_a A_a' (B_a v[cam(a)]): like k_backsub_st a wave owns 64 consecutive
-// points and walks their (contiguous) observations in batches of 64 staged rows, but the per-observation part -- B_a v, then
-// A_a' of it -- is done with ONE LANE PER OBSERVATION of the batch; the lanes then switch to their points and add up the
-// 3-vectors of their own observations from LDS.  (In k_backsub_st a lane does all of that for its point's observations one
-// after the other while the lanes of the other ~50 points of the wave have no observation in the batch.)
+// The point sweep, h_p = -U_p^-1 sum_a A_a' (B_a v[cam(a)]) (the PCG product; with FULL the back-substitution of every step):
+// a wave owns 64 consecutive points and walks their (contiguous) observations in batches of 64 staged rows; the
+// per-observation part -- B_a v, then A_a' of it -- is done with ONE LANE PER OBSERVATION of the batch, the lanes then switch
+// to their points and add up the 3-vectors of their own observations from LDS.  (The first staged version let a lane do all of
+// that for its point's observations one after the other, while the lanes of the other ~50 points of the wave had no
+// observation in the batch.)
+template <bool FULL>
 __global__ __launch_bounds__(BLK) void k_wtv(int64_t npnts, const int *__restrict__ pt_ptr, const int *__restrict__ cam0,
                                               const double *__restrict__ J, const double *__restrict__ Uinv,
-                                              const double *__restrict__ v, double *__restrict__ h) {
+                                              const double *__restrict__ v, double *__restrict__ h,
+                                              const double *__restrict__ u = nullptr, const double *__restrict__ r = nullptr,
+                                              double cr = 1.0, double *__restrict__ partial = nullptr) {
+  // FULL: the back-substitution of the direct path, h = -(u + U^-1 W' v), and -- r != null -- the model value of the step in
+  // a second sweep over the wave's rows, again one lane per observation: partial[blockIdx.x] = this block's part of
+  // sum |A h + B v + cr r|^2
   __shared__ double slots[(BLK / 64) * ST_WAVE_ELEMS];
   __shared__ double wb[(BLK / 64) * 64 * 3];
+  __shared__ double dpw[FULL ? (BLK / 64) * 64 * 3 : 1];
+  __shared__ int own[FULL ? BLK : 1];
+  __shared__ double red[BLK / 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t p0 = (int64_t)blockIdx.x * BLK + wv * 64;
-  if (p0 >= npnts) return;  // wave-uniform; no workgroup barrier below
-  double *slot = slots + wv * ST_WAVE_ELEMS, *wbuf = wb + wv * 64 * 3;
-  const int64_t p = p0 + lane, plast = p0 + 64 < npnts ? p0 + 64 : npnts;
-  const int qb = pt_ptr[p0], qe = pt_ptr[plast];
-  const int mb = p < npnts ? pt_ptr[p] : qe, me = p < npnts ? pt_ptr[p + 1] : qe;
-  double t[3] = {0, 0, 0};
-  d2n pv[12];
-  int cn = 0;
-  auto issue = [&](int q0) {  // the rows and camera indices of the next batch, requested before the current one is worked on
-    const int nrows = qe - q0 < 64 ? qe - q0 : 64;
-    cn = cam0[q0 + (lane < nrows ? lane : nrows - 1)];
-    stage_issue(J, nullptr, q0, nrows, pv);
-  };
-  if (qb < qe) issue(qb);
-  for (int q0 = qb; q0 < qe; q0 += 64) {
-    const int nrows = qe - q0 < 64 ? qe - q0 : 64;
-    const int ci = cn;
-    stage_commit(pv, slot);
-    if (q0 + 64 < qe) issue(q0 + 64);
-    if (lane < nrows) {
-      const double *Jo = slot + lane * JLD;
-      const double *d = v + 9 * (int64_t)ci;
-      double s0 = 0, s1 = 0;
+  double acc = 0;
+  if (p0 < npnts) {  // wave-uniform
+    double *slot = slots + wv * ST_WAVE_ELEMS, *wbuf = wb + wv * 64 * 3;
+    const int64_t p = p0 + lane, plast = p0 + 64 < npnts ? p0 + 64 : npnts;
+    const int qb = pt_ptr[p0], qe = pt_ptr[plast];
+    const int mb = p < npnts ? pt_ptr[p] : qe, me = p < npnts ? pt_ptr[p + 1] : qe;
+    double t[3] = {0, 0, 0};
+    d2n pv[12];
+    int cn = 0;
+    auto issue = [&](int q0) {  // the rows and camera indices of the next batch, requested before the current one is worked on
+      const int nrows = qe - q0 < 64 ? qe - q0 : 64;
+      cn = cam0[q0 + (lane < nrows ? lane : nrows - 1)];
+      stage_issue(J, nullptr, q0, nrows, pv);
+    };
+    if (qb < qe) issue(qb);
+    for (int q0 = qb; q0 < qe; q0 += 64) {
+      const int nrows = qe - q0 < 64 ? qe - q0 : 64;
+      const int ci = cn;
+      stage_commit(pv, slot);
+      if (q0 + 64 < qe) issue(q0 + 64);
+      if (lane < nrows) {
+        const double *Jo = slot + lane * JLD;
+        const double *d = v + 9 * (int64_t)ci;
+        double s0 = 0, s1 = 0;
 #pragma unroll
-      for (int i = 0; i < 9; i++) {
-        s0 += Jo[3 + i] * d[i];
-        s1 += Jo[15 + i] * d[i];
+        for (int i = 0; i < 9; i++) {
+          s0 += Jo[3 + i] * d[i];
+          s1 += Jo[15 + i] * d[i];
+        }
+        wbuf[3 * lane + 0] = Jo[0] * s0 + Jo[12] * s1;
+        wbuf[3 * lane + 1] = Jo[1] * s0 + Jo[13] * s1;
+        wbuf[3 * lane + 2] = Jo[2] * s0 + Jo[14] * s1;
       }
-      wbuf[3 * lane + 0] = Jo[0] * s0 + Jo[12] * s1;
-      wbuf[3 * lane + 1] = Jo[1] * s0 + Jo[13] * s1;
-      wbuf[3 * lane + 2] = Jo[2] * s0 + Jo[14] * s1;
+      wave_lds_sync();
+      const int lo = mb > q0 ? mb : q0, hi = me < q0 + 64 ? me : q0 + 64;
+      for (int q = lo; q < hi; q++) {
+        t[0] += wbuf[3 * (q - q0) + 0];
+        t[1] += wbuf[3 * (q - q0) + 1];
+        t[2] += wbuf[3 * (q - q0) + 2];
+      }
+      wave_lds_sync();  // slot and wbuf are rewritten by the next batch
     }
-    wave_lds_sync();
-    const int lo = mb > q0 ? mb : q0, hi = me < q0 + 64 ? me : q0 + 64;
-    for (int q = lo; q < hi; q++) {
-      t[0] += wbuf[3 * (q - q0) + 0];
-      t[1] += wbuf[3 * (q - q0) + 1];
-      t[2] += wbuf[3 * (q - q0) + 2];
+    double d3[3] = {0, 0, 0};
+    if (p < npnts) {
+      const double *U = Uinv + 6 * p;
+      if (FULL) {
+        d3[0] = -(u[3 * p + 0] + ((U[0] * t[0] + U[1] * t[1]) + U[2] * t[2]));
+        d3[1] = -(u[3 * p + 1] + ((U[1] * t[0] + U[3] * t[1]) + U[4] * t[2]));
+        d3[2] = -(u[3 * p + 2] + ((U[2] * t[0] + U[4] * t[1]) + U[5] * t[2]));
+      } else {
+        d3[0] = -((U[0] * t[0] + U[1] * t[1]) + U[2] * t[2]);
+        d3[1] = -((U[1] * t[0] + U[3] * t[1]) + U[4] * t[2]);
+        d3[2] = -((U[2] * t[0] + U[4] * t[1]) + U[5] * t[2]);
+      }
+      h[3 * p + 0] = d3[0];
+      h[3 * p + 1] = d3[1];
+      h[3 * p + 2] = d3[2];
     }
-    wave_lds_sync();  // slot and wbuf are rewritten by the next batch
+    if (FULL && r) {
+      double *dw = dpw + wv * 64 * 3;
+      int *ow = own + wv * 64;
+      dw[3 * lane + 0] = d3[0];
+      dw[3 * lane + 1] = d3[1];
+      dw[3 * lane + 2] = d3[2];
+      if (qb < qe) issue(qb);
+      for (int q0 = qb; q0 < qe; q0 += 64) {
+        const int nrows = qe - q0 < 64 ? qe - q0 : 64;
+        const int ci = cn;
+        const int lo = mb > q0 ? mb : q0, hi = me < q0 + 64 ? me : q0 + 64;
+        for (int q = lo; q < hi; q++) ow[q - q0] = lane;  // which lane holds the point of row q
+        stage_commit(pv, slot);                          // (its fence also publishes ow and, the first time, dw)
+        if (q0 + 64 < qe) issue(q0 + 64);
+        if (lane < nrows) {
+          const double *Jo = slot + lane * JLD;
+          const double *d = v + 9 * (int64_t)ci;
+          const double *dq = dw + 3 * ow[lane];
+          const int64_t q = q0 + lane;
+          double s0 = cr * r[2 * q], s1 = cr * r[2 * q + 1];
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            s0 += Jo[i] * dq[i];
+            s1 += Jo[12 + i] * dq[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 9; i++) {
+            s0 += Jo[3 + i] * d[i];
+            s1 += Jo[15 + i] * d[i];
+          }
+          acc += s0 * s0 + s1 * s1;
+        }
+        wave_lds_sync();
+      }
+    }
   }
-  if (p < npnts) {
-    const double *U = Uinv + 6 * p;
-    h[3 * p + 0] = -((U[0] * t[0] + U[1] * t[1]) + U[2] * t[2]);
-    h[3 * p + 1] = -((U[1] * t[0] + U[3] * t[1]) + U[4] * t[2]);
-    h[3 * p + 2] = -((U[2] * t[0] + U[4] * t[1]) + U[5] * t[2]);
+  if (FULL && r) {
+    acc = wave_sum(acc);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
   }
 }
 
@@ -1198,7 +1180,9 @@ int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const
   const unsigned nb = grid_for(p->npnts, BLK);
   if (p->point_sorted && staged_on()) {
     const bool with_model = d_r_model && d_partial && d_scal;
-    hipLaunchKernelGGL(k_backsub_st, dim3(nb), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->cam0, d_J, d_Uinv, d_u, d_dc, d_dp,
+    // one lane per observation in both sweeps (k_wtv<true>; the first staged version walked a point's observations with one
+    // lane: Venice 0.75 -> 0.33 ms, Dubrovnik 0.28 -> 0.10 ms per call)
+    hipLaunchKernelGGL(k_wtv<true>, dim3(nb), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->cam0, d_J, d_Uinv, d_dc, d_dp, d_u,
                        with_model ? d_r_model : (const double *)nullptr, cr, d_partial);
     if (with_model) {
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLK), 0, st, (int)nb, d_partial, d_scal, slot);
@@ -1337,7 +1321,7 @@ int launch_cg_beta_dir(ba_problem *p, int64_t n, const double *d_partial, double
 int launch_wtv(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_v, double *d_h, hipStream_t st) {
   if (p->npnts == 0) return BA_OK;
   ProfScope ps(p, PC_BACKSUB, st);
-  hipLaunchKernelGGL(k_wtv, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->cam0, d_J, d_Uinv, d_v, d_h);
+  hipLaunchKernelGGL(k_wtv<false>, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->cam0, d_J, d_Uinv, d_v, d_h);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
