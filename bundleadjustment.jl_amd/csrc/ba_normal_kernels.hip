@@ -931,6 +931,61 @@ __global__ __launch_bounds__(BLK) void k_wtv(int64_t npnts, const int *__restric
   }
 }
 
+// Hpp (6) and gp (3) per point for point-sorted observations, one lane per OBSERVATION for the nine products and one lane
+// per point for their sum (k_wtv's scheme; only the point part of a row is needed: plain 8-byte loads, no staging).
+__global__ __launch_bounds__(BLK) void k_point_blocks_lpo(int64_t npnts, const int *__restrict__ pt_ptr, const double *__restrict__ J,
+                                                           const double *__restrict__ r, double *__restrict__ Hpp,
+                                                           double *__restrict__ gp) {
+  __shared__ double vb[(BLK / 64) * 64 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t p0 = (int64_t)blockIdx.x * BLK + wv * 64;
+  if (p0 >= npnts) return;  // wave-uniform; no workgroup barrier below
+  double *vw = vb + wv * 64 * 9;
+  const int64_t p = p0 + lane, plast = p0 + 64 < npnts ? p0 + 64 : npnts;
+  const int qb = pt_ptr[p0], qe = pt_ptr[plast];
+  const int mb = p < npnts ? pt_ptr[p] : qe, me = p < npnts ? pt_ptr[p + 1] : qe;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q0 = qb; q0 < qe; q0 += 64) {
+    const int nrows = qe - q0 < 64 ? qe - q0 : 64;
+    if (lane < nrows) {
+      const int64_t o = q0 + lane;
+      const double *Jo = J + 24 * o;
+      const double a0[3] = {Jo[0], Jo[1], Jo[2]}, a1[3] = {Jo[12], Jo[13], Jo[14]};
+      double *w = vw + 9 * lane;
+      w[0] = a0[0] * a0[0] + a1[0] * a1[0];
+      w[1] = a0[0] * a0[1] + a1[0] * a1[1];
+      w[2] = a0[0] * a0[2] + a1[0] * a1[2];
+      w[3] = a0[1] * a0[1] + a1[1] * a1[1];
+      w[4] = a0[1] * a0[2] + a1[1] * a1[2];
+      w[5] = a0[2] * a0[2] + a1[2] * a1[2];
+      if (gp) {
+        const double r0 = r[2 * o], r1 = r[2 * o + 1];
+        w[6] = a0[0] * r0 + a1[0] * r1;
+        w[7] = a0[1] * r0 + a1[1] * r1;
+        w[8] = a0[2] * r0 + a1[2] * r1;
+      }
+    }
+    wave_lds_sync();
+    const int lo = mb > q0 ? mb : q0, hi = me < q0 + 64 ? me : q0 + 64;
+    for (int q = lo; q < hi; q++) {
+      const double *w = vw + 9 * (q - q0);
+#pragma unroll
+      for (int i = 0; i < 6; i++) acc[i] += w[i];
+      if (gp) {
+#pragma unroll
+        for (int i = 6; i < 9; i++) acc[i] += w[i];
+      }
+    }
+    wave_lds_sync();
+  }
+  if (p < npnts) {
+    if (Hpp)
+      for (int i = 0; i < 6; i++) Hpp[6 * p + i] = acc[i];
+    if (gp)
+      for (int i = 0; i < 3; i++) gp[3 * p + i] = acc[6 + i];
+  }
+}
+
 __global__ __launch_bounds__(BLK) void k_gather_int(int64_t n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ dst) {
   const int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
@@ -1068,8 +1123,11 @@ int launch_point_blocks(ba_problem *p, const double *d_J, const double *d_r, dou
                         hipStream_t st) {
   if (p->npnts == 0) return BA_OK;
   ProfScope ps(p, PC_POINT_BLOCKS, st);
-  hipLaunchKernelGGL(k_point_blocks, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->pt_obs,
-                     d_J, d_r, d_Hpp, d_gp);
+  if (p->point_sorted)
+    hipLaunchKernelGGL(k_point_blocks_lpo, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, p->pt_ptr, d_J, d_r, d_Hpp, d_gp);
+  else
+    hipLaunchKernelGGL(k_point_blocks, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, p->pt_ptr, p->pt_obs,
+                       d_J, d_r, d_Hpp, d_gp);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
