@@ -824,3 +824,26 @@ def test_lm_pcg_follows_the_oracle_through_rejections(ba, orc, small_prob, gpu_o
     assert n >= 3 and (linesearch or [bool(v) for v in log_ref[:n, 7]].count(False) >= 1)
     _compare_rows(st, log_ref, n)
     m.close()
+
+
+def test_pcg_only_handle_holds_nothing_of_the_size_of_S(ba, gpu_ok):
+    """The tiles of S, the panel buffers and the Schur task list are allocated by the first DIRECT solve: a handle that only
+    runs facto = :PCG must not grow by anything like n^2/2 doubles (2 000 cameras: S alone is 1.3 GB)."""
+    import torch
+    prob = ba.synthetic.make_problem(2000, 6000, 40000, seed=21)
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob))
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    d, half, _, its = ba.lm_step(m, prob["x0"], 10.0, pcg=(1e-10, 2000))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    grown = free0 - free1
+    s_bytes = (9 * 2000) ** 2 // 2 * 8
+    print(f"PCG step: {its} iterations, device memory grown by {grown / 1e6:.1f} MB (S would be {s_bytes / 1e6:.0f} MB)")
+    assert 0 < its < 2000 and grown < s_bytes // 4
+    d2, half2, _ = ba.lm_step(m, prob["x0"], 10.0)  # the direct solve then brings its workspace
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free1 - free2 > s_bytes // 2
+    assert np.linalg.norm(d - d2) <= 1e-7 * np.linalg.norm(d2)
+    m.close()
