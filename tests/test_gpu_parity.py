@@ -847,3 +847,29 @@ def test_pcg_only_handle_holds_nothing_of_the_size_of_S(ba, gpu_ok):
     assert free1 - free2 > s_bytes // 2
     assert np.linalg.norm(d - d2) <= 1e-7 * np.linalg.norm(d2)
     m.close()
+
+
+def test_bench_line_contract(gpu_ok, tmp_path):
+    """`python bench.py` prints ONE JSON line with the fields the driver reads (metric, value, unit, n_gpus, steps, warmup,
+    ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config.workload) plus roofline, cpu_baseline and the
+    secondary facto = :PCG measurement; run here on a scaled-down Venice shape."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scale", "0.05", "--steps", "4", "--warmup", "1",
+                        "--cpu-seconds", "1", "--cpu-full", "none"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "pcg"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-6 * 1e3
+    assert "workload" in d["config"] and d["vs_baseline"] is None and d["data"] == "synthetic"
+    roof = d["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["peak"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["pcg"]["value"] > 0 and abs(d["pcg"]["objective"] - d["pcg"]["objective_direct"]) <= 1e-8 * d["pcg"]["objective_direct"]
