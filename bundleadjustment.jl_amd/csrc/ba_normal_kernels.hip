@@ -470,7 +470,9 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
   // grid-stride over the keys: the AQL grid size is a 32-bit count of work-items, and Final-13682 has 93.6 M keys
   // (x 64 lanes > 2^32): a one-wave-per-key launch silently dropped the tail (zero pivots at the first lost diagonal).
   // (Tried: giving each XCD a contiguous eighth of the (camera_a, camera_b)-sorted keys so that a camera's own rows are
-  // re-read from that XCD's L2 -- 4.3 -> 5.1 ms on Venice, slower: the interleaved order stays.)
+  // re-read from that XCD's L2 -- 4.3 -> 5.1 ms on Venice in round 1's kernel, 3.73 -> 3.67 ms in this one: the L2-miss traffic
+  // (9.5 GB per launch against 3.4 GB if every row were fetched once per XCD that needs it) is served by the MALL and does not
+  // bound the kernel; the interleaved order stays.)
   for (int64_t key = (int64_t)blockIdx.x * (BLK / 64) + wv; key < nkeys; key += (int64_t)gridDim.x * (BLK / 64)) {
     const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
     if (split_above > 0 && t_end - t_begin > split_above) continue;
