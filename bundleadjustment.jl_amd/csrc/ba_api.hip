@@ -315,18 +315,29 @@ extern "C" int ba_dev_free(ba_problem *p, void *d_ptr) {
   if (d_ptr) BA_HIP_CHECK(hipFree(d_ptr));
   return BA_OK;
 }
-extern "C" int ba_memcpy_h2d(ba_problem *p, void *d_dst, const void *h_src, size_t bytes) {
-  if (!p) return BA_ERR_ARG;
+// Copies between host and device memory are ORDERED ON A STREAM and complete on return: the copy is enqueued on `stream`
+// (null: the handle's own stream), behind everything enqueued there before, and the call returns when that stream has
+// drained.  A null-stream hipMemcpy has no ordering against the library's hipStreamNonBlocking streams: data it writes is
+// not ordered before (nor made visible to) kernels launched afterwards on a stream the host never synchronised.
+static int copy_on(ba_problem *p, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, void *stream) {
+  if (!p || (bytes && (!dst || !src))) return BA_ERR_ARG;
   BA_HIP_CHECK(hipSetDevice(p->device));
-  BA_HIP_CHECK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+  if (bytes) BA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, st));
+  BA_HIP_CHECK(hipStreamSynchronize(st));
   return BA_OK;
 }
+extern "C" int ba_memcpy_h2d(ba_problem *p, void *d_dst, const void *h_src, size_t bytes) {
+  return copy_on(p, d_dst, h_src, bytes, hipMemcpyHostToDevice, nullptr);
+}
 extern "C" int ba_memcpy_d2h(ba_problem *p, void *h_dst, const void *d_src, size_t bytes) {
-  if (!p) return BA_ERR_ARG;
-  BA_HIP_CHECK(hipSetDevice(p->device));
-  BA_HIP_CHECK(hipStreamSynchronize(p->stream));  // the handle's stream is non-blocking: drain it first
-  BA_HIP_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
-  return BA_OK;
+  return copy_on(p, h_dst, d_src, bytes, hipMemcpyDeviceToHost, nullptr);
+}
+extern "C" int ba_memcpy_h2d_on(ba_problem *p, void *stream, void *d_dst, const void *h_src, size_t bytes) {
+  return copy_on(p, d_dst, h_src, bytes, hipMemcpyHostToDevice, stream);
+}
+extern "C" int ba_memcpy_d2h_on(ba_problem *p, void *stream, void *h_dst, const void *d_src, size_t bytes) {
+  return copy_on(p, h_dst, d_src, bytes, hipMemcpyDeviceToHost, stream);
 }
 extern "C" int ba_synchronize(ba_problem *p) {
   if (!p) return BA_ERR_ARG;

@@ -18,6 +18,7 @@
 #include "ba_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1247,8 +1248,8 @@ int64_t dense_ldl_tiles_doubles(int64_t n_unpadded) {
 
 template <typename T>
 static int set_kernel_attrs() {
-  static bool g_attr_done = false;
-  if (g_attr_done) return BA_OK;
+  static std::atomic<bool> g_attr_done{false};
+  if (g_attr_done.load()) return BA_OK;
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_diag<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1>),
@@ -1263,7 +1264,7 @@ static int set_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PT_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 0, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_priv_lds_bytes<T>()));
-  g_attr_done = true;
+  g_attr_done.store(true);
   return BA_OK;
 }
 
@@ -1319,11 +1320,16 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
   BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(T)));
   // k_ldl_diag writes the lower triangle of each inverse only; the consumers read whole tiles
   BA_HIP_CHECK(hipMemset(w->Linv, 0, (size_t)nt * NB * NB * sizeof(T)));
+  BA_HIP_CHECK(hipDeviceSynchronize());  // (a null-stream memset is not ordered against the non-blocking streams that use Linv)
   BA_HIP_CHECK(hipMalloc((void **)&w->D, (size_t)nt * NB * 2 * sizeof(T)));  // D | y scratch
   BA_HIP_CHECK(hipMalloc((void **)&w->flag, sizeof(int)));
   BA_HIP_CHECK(hipMalloc((void **)&w->ready, (size_t)nt * sizeof(int)));
   BA_HIP_CHECK(hipStreamCreateWithFlags(&w->hoist, hipStreamNonBlocking));
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_top, hipEventDisableTiming | hipEventReleaseToDevice));
+  // the distributed factorisation's events order work whose data LEAVES the device (panels handed to the transport):
+  // default release scope, not hipEventReleaseToDevice as the single-GPU hoist events above
+  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_dtop, hipEventDisableTiming));
+  BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_dchain, hipEventDisableTiming));
   for (int q = 0; q < 2; q++) {
     BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_recv[q], hipEventDisableTiming));
     BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_upd[q], hipEventDisableTiming));
@@ -1356,6 +1362,8 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->hoist) (void)hipStreamDestroy(w->hoist);
   if (w->ev_top) (void)hipEventDestroy(w->ev_top);
   if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
+  if (w->ev_dtop) (void)hipEventDestroy(w->ev_dtop);
+  if (w->ev_dchain) (void)hipEventDestroy(w->ev_dchain);
   for (int q = 0; q < 2; q++) {
     if (w->ev_recv[q]) (void)hipEventDestroy(w->ev_recv[q]);
     if (w->ev_upd[q]) (void)hipEventDestroy(w->ev_upd[q]);
@@ -1608,7 +1616,8 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
   T *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
   BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
   w->hoisting = false;
-  static const bool la_off = [] { const char *e = getenv("BA_DIST_LOOKAHEAD"); return e && e[0] == '0'; }();
+  const char *la_env = getenv("BA_DIST_LOOKAHEAD");  // read per call: a test flips it between two factorisations of one process
+  const bool la_off = la_env && la_env[0] == '0';
   const int M = (int)w->h_own_cols.size();
   auto own_from = [&](int base) {  // index of the first owned tile column >= base
     return (int)(std::lower_bound(w->h_own_cols.begin(), w->h_own_cols.end(), base) - w->h_own_cols.begin());
@@ -1624,12 +1633,12 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
     }
   } else {
     hipStream_t cs = w->hoist;  // transfer stream
-    BA_HIP_CHECK(hipEventRecord(w->ev_top, st));  // fork: behind the reduce of S
-    BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_top, 0));
+    BA_HIP_CHECK(hipEventRecord(w->ev_dtop, st));  // fork: behind the reduce of S
+    BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_dtop, 0));
     if (0 % P == me) {
       BA_CHECK(dist_chain(p, w, 0, Vs[0][0], Vs[0][1], st));
-      BA_HIP_CHECK(hipEventRecord(w->ev_chain, st));
-      BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_chain, 0));
+      BA_HIP_CHECK(hipEventRecord(w->ev_dchain, st));
+      BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_dchain, 0));
     }
     BA_CHECK(dist_transfer(p, w, 0, Vs[0][0], Vs[0][1], 0, cs));
     BA_HIP_CHECK(hipEventRecord(w->ev_recv[0], cs));
@@ -1644,13 +1653,13 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
         const int lead = (k + 3 < nt) ? 2 : 1;
         BA_CHECK(launch_pair_owned(p, w, k, V0, V1, st, m0, m0 + lead));
         BA_CHECK(dist_chain(p, w, k + 2, N0, N1, st));
-        BA_HIP_CHECK(hipEventRecord(w->ev_chain, st));
+        BA_HIP_CHECK(hipEventRecord(w->ev_dchain, st));
         m0 += lead;
       }
       BA_CHECK(launch_pair_owned(p, w, k, V0, V1, st, m0, M));
       BA_HIP_CHECK(hipEventRecord(w->ev_upd[q & 1], st));
       if (q >= 1) BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_upd[(q + 1) & 1], 0));  // update q-1 has read Vs[(q+1)&1]
-      if (next_mine) BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_chain, 0));
+      if (next_mine) BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_dchain, 0));
       BA_CHECK(dist_transfer(p, w, k + 2, N0, N1, (q + 1) % P, cs));
       BA_HIP_CHECK(hipEventRecord(w->ev_recv[(q + 1) & 1], cs));
     }

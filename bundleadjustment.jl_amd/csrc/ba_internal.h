@@ -90,6 +90,7 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   hipEvent_t ev_chain = nullptr;  // recorded behind each hoisted diagonal kernel
   // distributed factorisation with look-ahead: panels of pair q received (transfer stream), update of pair q launched
   hipEvent_t ev_recv[2] = {nullptr, nullptr}, ev_upd[2] = {nullptr, nullptr};
+  hipEvent_t ev_dtop = nullptr, ev_dchain = nullptr;  // distributed factorisation: fork behind the reduce of S, end of the owner's panel chain
 };
 typedef DenseLDLT<double> DenseLDL;
 

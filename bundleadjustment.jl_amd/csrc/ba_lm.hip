@@ -272,6 +272,7 @@ static int lm_ensure(ba_problem *p) {
   w->hdiag = w->gc + w->npad;
   w->scal = w->s.red + w->s.off_scal;
   BA_HIP_CHECK(hipMemset(w->s.red + w->s.off_rhs, 0, (size_t)(w->s.red_doubles - w->s.off_rhs) * sizeof(double)));
+  BA_HIP_CHECK(hipDeviceSynchronize());  // (null-stream memset: not ordered against the handle's non-blocking stream)
   BA_CHECK(dmalloc(&w->x, w->nvar));
   BA_CHECK(dmalloc(&w->x_trial, w->nvar));
   BA_CHECK(dmalloc(&w->delta, w->nvar));
@@ -432,6 +433,7 @@ static int ensure_pcg(ba_problem *p, LMWorkFull *w) {
   BA_CHECK(dm(&w->zero3, 3 * p->npnts));
   BA_CHECK(dm(&w->blk45, 45 * p->ncams));
   BA_CHECK(dm(&w->cg_scal, 8));
+  BA_HIP_CHECK(hipDeviceSynchronize());  // (the null-stream memsets above are not ordered against the handle's stream)
   BA_HIP_CHECK(hipHostMalloc((void **)&w->h_cg, 8 * sizeof(double)));
   return BA_OK;
 }
@@ -646,8 +648,8 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
     BA_CHECK(step_scalars(p, w, st));
     BA_CHECK(trial_point(p, w, st, xf32));
     BA_CHECK(comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st));
-    BA_CHECK(fetch_scalars(p, w, st));
-    BA_HIP_CHECK(hipMemcpy(w->h_flag, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost));
+    BA_HIP_CHECK(hipMemcpyAsync(w->h_flag, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    BA_CHECK(fetch_scalars(p, w, st));  // (synchronises st)
     if (hoist_gave_up(w)) return trial_step(p, w, lambda, normalize, facto_f32, xf32, st);
     return BA_OK;
   }

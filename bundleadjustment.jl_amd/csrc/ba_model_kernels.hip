@@ -7,6 +7,7 @@
 // :161-206 + src/JacobianByHand.jl:5-101 (values).  Compiled with -ffp-contract=off: Julia does not
 // contract a*b+c, and the parity tests bound the distance to the reference evaluation order in ulps.
 #include <cstdlib>
+#include <mutex>
 
 #include "ba_internal.h"
 
@@ -509,6 +510,8 @@ static unsigned jac_grid(ba_problem *p, K kernel, int64_t nobs) {
   struct Entry { const void *k; int dev, per_cu, ncu; };
   static Entry cache[32];
   static int ncache = 0;
+  static std::mutex mu;  // handles may be driven from several host threads (one rank per thread in the loopback tests)
+  std::lock_guard<std::mutex> lock(mu);
   int per_cu = 0, ncu = 0;
   for (int q = 0; q < ncache; q++)
     if (cache[q].k == (const void *)kernel && cache[q].dev == p->device) {

@@ -100,11 +100,18 @@ class CameraBlockReducer:
         h = nlp.handle
 
         def _hook(ctx, op, d_buf, count, root, stream):
+            # Every copy is enqueued ON THE STREAM THE LIBRARY HANDS OVER (ba_memcpy_*_on) and that stream is drained: the
+            # operation is ordered behind the producer of d_buf and ahead of what the library launches next on `stream`
+            # (include/ba_hip.h).  `stream` is the transfer stream of the distributed factorisation's look-ahead as often as
+            # the handle's main stream; both are non-blocking, a null-stream copy has no ordering against either.
             try:
                 esize, view = {_lib.COMM_BCAST_BYTES: (1, np.uint8), _lib.COMM_REDUCE_F32: (4, np.float32)}.get(op, (8, np.float64))
                 nbytes = esize * count
                 host = np.empty(nbytes, dtype=np.uint8)
-                _lib.check(L.ba_memcpy_d2h(h, _lib.ptr(host), C.c_void_p(d_buf), nbytes))  # drains the handle's stream first
+                st = C.c_void_p(stream)
+                sends = not (op == _lib.COMM_BCAST_BYTES and self.rank != root)  # a broadcast's receivers have nothing to read
+                if sends:
+                    _lib.check(L.ba_memcpy_d2h_on(h, st, _lib.ptr(host), C.c_void_p(d_buf), nbytes))
                 t = torch.from_numpy(host.view(view))
                 src = (lambda r: dist.get_global_rank(group, r) if group is not None else r)
                 if op == _lib.COMM_ALLREDUCE_F64:
@@ -119,7 +126,7 @@ class CameraBlockReducer:
                         return 0
                 else:
                     return 2
-                _lib.check(L.ba_memcpy_h2d(h, C.c_void_p(d_buf), _lib.ptr(host), nbytes))
+                _lib.check(L.ba_memcpy_h2d_on(h, st, C.c_void_p(d_buf), _lib.ptr(host), nbytes))
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
                 import sys

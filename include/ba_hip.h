@@ -102,8 +102,15 @@ int ba_jtr_dev(ba_problem *p, const double *d_vals, const double *d_r, double *d
 /* small device-memory helpers so that a C / Julia caller needs no HIP binding of its own */
 int ba_dev_malloc(ba_problem *p, size_t bytes, void **d_ptr);
 int ba_dev_free(ba_problem *p, void *d_ptr);
+/* Host <-> device copies, ordered on a stream and complete on return: enqueued on the handle's own stream (the _on forms:
+ * on `stream`, a hipStream_t; NULL = the handle's stream) behind the work already enqueued there; the call returns when
+ * that stream has drained.  A communication hook (ba_lm_set_comm_hook) that stages through host memory must use the _on
+ * forms with the stream it was given: the library's streams are non-blocking, so a copy on any other stream is neither
+ * ordered behind the producer of the data nor visible to the kernels the library launches next on `stream`. */
 int ba_memcpy_h2d(ba_problem *p, void *d_dst, const void *h_src, size_t bytes);
 int ba_memcpy_d2h(ba_problem *p, void *h_dst, const void *d_src, size_t bytes);
+int ba_memcpy_h2d_on(ba_problem *p, void *stream, void *d_dst, const void *h_src, size_t bytes);
+int ba_memcpy_d2h_on(ba_problem *p, void *stream, void *h_dst, const void *d_src, size_t bytes);
 int ba_synchronize(ba_problem *p);
 
 /* ---- Levenberg_Marquardt(model, facto, perm, normalize[, linesearch]; kwargs...) --------------
@@ -179,7 +186,11 @@ int ba_lm_solve(ba_problem *p, const ba_lm_opts *opts, double *x_inout, ba_lm_st
  *                         BA_COMM_REDUCE_F64 / BA_COMM_REDUCE_F32 (count doubles / floats, the sum lands on `root` only,
  *                         in place; the Float32 form carries the reduced camera matrix of facto_type = Float32 runs),
  *                         BA_COMM_BCAST_BYTES (count bytes from `root`).  d_buf is a device pointer; the operation must
- *                         be ordered after prior work on `stream` and complete (or stream-ordered) on return. */
+ *                         be ordered after prior work on `stream` and complete (or stream-ordered ON `stream`) on return:
+ *                         `stream` is not always the handle's main stream (the distributed factorisation hands its
+ *                         panels over on a second, transfer stream while the trailing update runs on the main one), and
+ *                         both are hipStreamNonBlocking -- a host-staged hook copies with ba_memcpy_d2h_on /
+ *                         ba_memcpy_h2d_on(p, stream, ...), never on the null stream. */
 enum { BA_COMM_ALLREDUCE_F64 = 0, BA_COMM_REDUCE_F64 = 1, BA_COMM_BCAST_BYTES = 2, BA_COMM_REDUCE_F32 = 3 };
 #define BA_COMM_ID_BYTES 128
 typedef int (*ba_comm_fn)(void *ctx, int op, void *d_buf, int64_t count, int root, void *stream);

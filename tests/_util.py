@@ -1,0 +1,36 @@
+"""Small helpers shared by the GPU tests: self-describing comparisons (a failure names the field, the count and the place
+of the differences -- never a dump of the arrays)."""
+import hashlib
+
+import numpy as np
+
+
+def digest(a):
+    """short sha1 of an array's bytes"""
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def bits_report(a, b, name="array"):
+    """'' when a and b are bit-identical, else one line: digests, number of differing entries, the first differing index
+    with both values (hex), the largest relative difference."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.shape != b.shape:
+        return f"{name}: shapes differ {a.shape} vs {b.shape}"
+    ua, ub = a.view(np.uint8).reshape(a.size, -1), b.view(np.uint8).reshape(b.size, -1)
+    diff = np.flatnonzero(np.any(ua != ub, axis=1))
+    if diff.size == 0:
+        return ""
+    i = int(diff[0])
+    fa, fb = a.ravel()[i], b.ravel()[i]
+    scale = np.maximum(np.abs(a.ravel()), np.abs(b.ravel()))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.abs(a.ravel() - b.ravel()) / np.where(scale > 0, scale, 1.0)
+    hx = (lambda v: float(v).hex()) if a.dtype.kind == "f" else repr
+    return (f"{name}: NOT bit-identical -- digests {digest(a)} vs {digest(b)}; {diff.size} of {a.size} entries differ; first at "
+            f"[{i}]: {hx(fa)} vs {hx(fb)}; max relative difference {np.nanmax(rel):.3e}"
+            f"{'; non-finite values present' if not (np.all(np.isfinite(a)) and np.all(np.isfinite(b))) else ''}")
+
+
+def rel_err(a, b):
+    nb = np.linalg.norm(b)
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / (nb if nb > 0 else 1.0))

@@ -59,6 +59,8 @@ def main():
         out["step_wide"] = float(np.linalg.norm(dw - dw_ref) / np.linalg.norm(dw_ref))
         out["half_wide"] = float(abs(halfw - halfw_ref) / halfw_ref)
         out["wide_hex"] = [float(v).hex() for v in dw[-9 * wide["ncams"]:]]
+        import hashlib
+        out["wide_digest"] = hashlib.sha1(np.ascontiguousarray(dw[-9 * wide["ncams"]:]).tobytes()).hexdigest()[:16]
         out["step_pcg"] = float(np.linalg.norm(dpcg - dw_ref) / np.linalg.norm(dw_ref))
         out["half_pcg"] = float(abs(halfpcg - halfw_ref) / halfw_ref)
     # (b) complete LM runs

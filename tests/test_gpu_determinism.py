@@ -1,0 +1,208 @@
+"""Determinism of the device path (same input, same process, same schedule -> the same bits) and the multi-rank path on
+ONE GPU in ONE process with genuinely asynchronous streams (tests/helpers/ba_loopback.hip: every rank is a handle driven by
+its own host thread; reduce / broadcast are stream-ordered device copies, no host thread waits for the GPU).
+
+Why these exist: round 2's driver run failed `test_dist_lookahead_equals_alternating_schedule` on one box and passed it on
+another.  The host-staged hook copied with null-stream hipMemcpy while the look-ahead launches the consumers of those copies
+on a second non-blocking stream the host had not synchronised ("What went wrong in round 2")."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from _util import bits_report, digest, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOOPBACK = os.path.join(ROOT, "tests", "helpers", "libba_loopback.so")
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- one process, one rank: the same call twice gives the same bits ------------------------------------------------------
+@pytest.mark.parametrize("n,schedule", [(1800, "in order (15 tile rows)"), (4480, "hoisted diagonal tile (35 tile rows)"),
+                                        (8100, "fused pair schedule (64 tile rows)")])
+def test_dense_factorisation_twice_same_bits(ba, gpu_ok, n, schedule):
+    """The dense blocked LDL' on the same matrix twice in one process: bit-equal solutions, for each of the three
+    single-GPU schedules (the hoisted / fused ones run a workgroup BESIDE the trailing update and join it by a flag and an
+    event: a missing fence there would show as run-to-run differences)."""
+    rng = np.random.default_rng(n)
+    R = rng.standard_normal((n, n))
+    A = R + R.T
+    del R
+    A[np.diag_indices(n)] += 4 * np.sqrt(n)
+    b = rng.standard_normal(n)
+    x1, _ = ba._lib.dense_ldl_solve(A, b)
+    x2, _ = ba._lib.dense_ldl_solve(A, b)
+    res = np.linalg.norm(A @ x1 - b) / np.linalg.norm(b)
+    assert res < 1e-12, f"n = {n} ({schedule}): residual {res:.3e}"
+    rep = bits_report(x1, x2, f"dense LDL' solution, n = {n}, {schedule}, run 1 vs run 2")
+    assert not rep, rep
+    x3, _ = ba._lib.dense_ldl_solve(A, b, f32=True)
+    x4, _ = ba._lib.dense_ldl_solve(A, b, f32=True)
+    rep = bits_report(x3, x4, f"Float32 dense LDL' solution, n = {n}, {schedule}, run 1 vs run 2")
+    assert not rep, rep
+
+
+def test_lm_step_twice_same_bits_venice_scaled(ba, gpu_ok):
+    """One ba_lm_step on a Venice-shaped problem at a quarter of its size (445 cameras: n = 4005, 32 tile rows; 1.25 M
+    observations) twice on one handle, then on a second handle: residual, Jacobian, normal-equation blocks, Schur assembly
+    (split keys + fixed-order combine), factorisation, solves and back-substitution give the same bits every time."""
+    p = ba.synthetic.make_named("venice-1778", scale=0.25)
+    arrays = ba.synthetic.as_arrays(p)
+    m = ba.BALNLPModel(arrays=arrays)
+    d1, h1, g1 = ba.lm_step(m, p["x0"], 30.0)
+    d2, h2, g2 = ba.lm_step(m, p["x0"], 30.0)
+    m.close()
+    m = ba.BALNLPModel(arrays=arrays)
+    d3, h3, g3 = ba.lm_step(m, p["x0"], 30.0)
+    d32a, _, _ = ba.lm_step(m, p["x0"], 30.0, facto_type=np.float32)
+    d32b, _, _ = ba.lm_step(m, p["x0"], 30.0, facto_type=np.float32)
+    m.close()
+    assert np.all(np.isfinite(d1))
+    for tag, (a, b) in {"step, same handle": (d1, d2), "step, fresh handle": (d1, d3), "J'r, same handle": (g1, g2),
+                        "J'r, fresh handle": (g1, g3), "Float32-factor step, same handle": (d32a, d32b)}.items():
+        rep = bits_report(a, b, tag)
+        assert not rep, rep
+    assert h1 == h2 == h3, f"model value differs between runs: {h1!r} {h2!r} {h3!r}"
+
+
+# ---- several ranks in one process over the stream-ordered loopback transport ------------------------------------------------
+@pytest.fixture(scope="module")
+def loopback(gpu_ok):
+    assert os.path.exists(LOOPBACK), f"{LOOPBACK} is missing: __graft_entry__.build() compiles it"
+    L = C.CDLL(LOOPBACK)
+    L.ba_loopback_create.restype = C.c_void_p
+    L.ba_loopback_create.argtypes = [C.c_int, C.c_size_t]
+    L.ba_loopback_destroy.argtypes = [C.c_void_p]
+    L.ba_loopback_rank.restype = C.c_void_p
+    L.ba_loopback_rank.argtypes = [C.c_void_p, C.c_int]
+    L.ba_loopback_ops.restype = C.c_long
+    L.ba_loopback_ops.argtypes = [C.c_void_p]
+    return L
+
+
+class _Ranks:
+    """`world` shards of one problem as handles in this process, attached to one loopback communicator."""
+
+    def __init__(self, ba, L, prob, world, stage_mb=64):
+        self.ba, self.L, self.world, self.prob = ba, L, world, prob
+        arrays = ba.synthetic.as_arrays(prob)
+        self.loop = L.ba_loopback_create(world, stage_mb << 20)
+        assert self.loop, "loopback communicator could not be created"
+        hook = C.cast(L.ba_loopback_hook, ba._lib.COMM_CB)
+        self.shards, self.models = [], []
+        for r in range(world):
+            local, info = ba.parallel.shard_problem(arrays, r, world)
+            m = ba.BALNLPModel(arrays=local, device=0)
+            ba._lib.check(ba._lib.lib().ba_lm_set_comm_hook(m.handle, r, world, hook, L.ba_loopback_rank(self.loop, r)))
+            self.shards.append((local, info))
+            self.models.append(m)
+
+    def step(self, lam, **kw):
+        """one sharded LM step, every rank on its own host thread -> (global delta from rank 0's cameras, per-rank camera
+        parts, model value)"""
+        out, err = [None] * self.world, [None] * self.world
+
+        def run(r):
+            try:
+                out[r] = self.ba.lm_step(self.models[r], self.shards[r][0][3], lam, **kw)
+            except Exception as e:  # noqa: BLE001 -- reported below with the rank
+                err[r] = e
+
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(self.world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        bad = [(r, e) for r, e in enumerate(err) if e is not None]
+        assert not bad, f"rank(s) failed: {bad}"
+        ncams, npnts = self.prob["ncams"], self.prob["npnts"]
+        delta = np.zeros(3 * npnts + 9 * ncams)
+        cams = []
+        for r in range(self.world):
+            pb, pe = self.shards[r][1]["point_range"]
+            d = out[r][0]
+            delta[3 * pb:3 * pe] = d[:3 * (pe - pb)]
+            cams.append(d[3 * (pe - pb):].copy())
+        delta[3 * npnts:] = cams[0]
+        return delta, cams, out[0][1]
+
+    def close(self):
+        for m in self.models:
+            m.close()
+        self.L.ba_loopback_destroy(self.loop)
+
+
+def _set_lookahead(on):
+    if on:
+        os.environ.pop("BA_DIST_LOOKAHEAD", None)
+    else:
+        os.environ["BA_DIST_LOOKAHEAD"] = "0"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_loopback_sharded_step_equals_one_rank(ba, loopback, world):
+    """Observations sharded by point over 2 / 3 ranks of ONE process, reduce of the reduced camera matrix onto the owners,
+    distributed factorisation with look-ahead on asynchronous streams: the step of the unsharded problem to rounding
+    (Float64) / Float32 level (facto_type = Float32), the camera part bit-identical on every rank."""
+    prob = ba.synthetic.make_problem(200, 1500, 9000, seed=11)  # n = 1800: 15 tile rows, 8 tile column pairs
+    ref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob))
+    d_ref, half_ref, _ = ba.lm_step(ref, prob["x0"], 10.0)
+    d32_ref, _, _ = ba.lm_step(ref, prob["x0"], 10.0, facto_type=np.float32)
+    ref.close()
+    _set_lookahead(True)
+    R = _Ranks(ba, loopback, prob, world)
+    try:
+        d, cams, half = R.step(10.0)
+        e = rel_err(d, d_ref)
+        assert e <= 1e-9, f"{world} ranks, Float64: |delta - delta_one_rank| / |delta_one_rank| = {e:.3e} (limit 1e-9)"
+        assert abs(half - half_ref) <= 1e-10 * half_ref, f"{world} ranks: model value {half!r} vs {half_ref!r}"
+        for r in range(1, world):
+            rep = bits_report(cams[0], cams[r], f"camera step of rank 0 vs rank {r} (replicated solve)")
+            assert not rep, rep
+        d32, cams32, _ = R.step(10.0, facto_type=np.float32)
+        e32 = rel_err(d32, d32_ref)
+        assert e32 <= 5e-3, f"{world} ranks, Float32 factor: relative step difference {e32:.3e} (limit 5e-3)"
+        for r in range(1, world):
+            rep = bits_report(cams32[0], cams32[r], f"Float32-factor camera step of rank 0 vs rank {r}")
+            assert not rep, rep
+        dp, _, _ = R.step(10.0, pcg=(1e-12, 5000))[:3]
+        ep = rel_err(dp, d_ref)
+        assert ep <= 1e-8, f"{world} ranks, facto = :PCG: relative step difference {ep:.3e} (limit 1e-8)"
+        assert loopback.ba_loopback_ops(R.loop) > 0
+    finally:
+        R.close()
+
+
+@pytest.mark.parametrize("ncams,npnts,nobs", [(200, 1500, 9000), (640, 5000, 36000)])
+def test_loopback_lookahead_same_bits_as_alternating(ba, loopback, ncams, npnts, nobs):
+    """Distributed factorisation on 3 ranks with asynchronous streams: the look-ahead schedule (owner of the next pair
+    updates its leading columns first, chain + panel hand-over on the transfer stream beside the rest of the update)
+    against the strictly alternating one (BA_DIST_LOOKAHEAD=0) -- the same products in the same order, so the SAME BITS;
+    and the look-ahead run twice gives the same bits (n = 1800: 8 tile column pairs; n = 5760: 23 pairs, updates long
+    enough to overlap the transfers for real)."""
+    prob = ba.synthetic.make_problem(ncams, npnts, nobs, seed=11)
+    ref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob))
+    d_ref, _, _ = ba.lm_step(ref, prob["x0"], 10.0)
+    ref.close()
+    R = _Ranks(ba, loopback, prob, 3, stage_mb=256)
+    try:
+        runs = {}
+        for tag, on in (("look-ahead, run 1", True), ("alternating", False), ("look-ahead, run 2", True)):
+            _set_lookahead(on)
+            d, cams, _ = R.step(10.0)
+            e = rel_err(d, d_ref)
+            assert e <= 1e-9, f"{tag}: relative difference to the one-rank step {e:.3e} (limit 1e-9)"
+            for r in (1, 2):
+                rep = bits_report(cams[0], cams[r], f"{tag}: camera step of rank 0 vs rank {r}")
+                assert not rep, rep
+            runs[tag] = cams[0]
+        print({k: digest(v) for k, v in runs.items()})
+        for tag in ("alternating", "look-ahead, run 2"):
+            rep = bits_report(runs["look-ahead, run 1"], runs[tag], f"camera step, look-ahead run 1 vs {tag}")
+            assert not rep, rep
+    finally:
+        _set_lookahead(True)
+        R.close()
