@@ -770,6 +770,25 @@ extern "C" int ba_lm_step_f32(ba_problem *p, const double *x, double lambda, dou
   return lm_step_impl(p, x, lambda, delta, half_sq_model, jtr, true);
 }
 
+// A scalar with the width Julia's promotion rules give it: an operation rounds to Float32 exactly when both operands are
+// Float32 (Base promotion: Float32 op Float64 -> Float64).  Used by ba_lm_solve for Float32 models.
+namespace ts {
+struct TS {
+  double v;
+  int w;  // 32 | 64
+};
+static inline TS f32(double x) { return TS{(double)(float)x, 32}; }
+static inline TS f64(double x) { return TS{x, 64}; }
+static inline bool both32(TS a, TS b) { return a.w == 32 && b.w == 32; }
+static inline TS add(TS a, TS b) { return both32(a, b) ? f32((float)a.v + (float)b.v) : f64(a.v + b.v); }
+static inline TS sub(TS a, TS b) { return both32(a, b) ? f32((float)a.v - (float)b.v) : f64(a.v - b.v); }
+static inline TS mul(TS a, TS b) { return both32(a, b) ? f32((float)a.v * (float)b.v) : f64(a.v * b.v); }
+static inline TS div(TS a, TS b) { return both32(a, b) ? f32((float)a.v / (float)b.v) : f64(a.v / b.v); }
+static inline TS max(TS a, TS b) { return TS{a.v > b.v ? a.v : b.v, both32(a, b) ? 32 : 64}; }
+static inline TS sqrt(TS a) { return a.w == 32 ? f32(std::sqrt((float)a.v)) : f64(std::sqrt(a.v)); }
+static inline TS powi(TS a, int n) { return a.w == 32 ? f32(std::pow((float)a.v, (float)n)) : f64(std::pow(a.v, (double)n)); }
+}  // namespace ts
+
 extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, ba_lm_stats *stats, ba_log_cb cb,
                            void *cb_ctx) {
   if (!p || !o || !x_inout || !stats) {
@@ -817,18 +836,38 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   w->pcg_maxit = o->pcg_max_iter > 0 ? o->pcg_max_iter : 0;
   w->n_cg = 0;
   if (!w->pcg) BA_CHECK(ensure_dense(p, w));  // (here, not in linear_step: no allocation while a graph is being recorded)
-  const double eps = xf32 ? 1.1920928955078125e-07 : 2.220446049250313e-16, sq = std::sqrt(eps), cbr = std::pow(eps, 1.0 / 3.0);
-  const double restol = o->restol >= 0 ? o->restol : (V ? cbr : 100 * sq);
-  const double satol = o->satol >= 0 ? o->satol : sq, srtol = o->srtol >= 0 ? o->srtol : sq;
-  const double oatol = o->oatol >= 0 ? o->oatol : sq, ortol = o->ortol >= 0 ? o->ortol : (V ? cbr : 1000 * sq);
-  const double atol = o->atol >= 0 ? o->atol : (V ? sq : 100 * sq), rtol = o->rtol >= 0 ? o->rtol : (V ? cbr : 1000 * sq);
-  const double nu_d = o->nu_d > 0 ? o->nu_d : 3, nu_m = o->nu_m > 0 ? o->nu_m : 3;
-  double lambda = o->lambda > 0 ? o->lambda : (V ? 30 : 0.1);
-  const double delta_d = o->delta_d > 0 ? o->delta_d : 2;
+  // Scalars carry the width Julia's promotion rules give them (TS: value + 32 | 64).  For a Float64 model everything is
+  // a Float64 and the arithmetic below is plain double arithmetic.  For eltype(x) = Float32 (src/lm.jl:20-26,36-59):
+  // norm() of a Float32 vector, obj = norm_r^2 / 2, pred, ared, rho are Float32; the eps(Float32)-derived default
+  // tolerances and nu_d, nu_m, delta_d, lambda are Float32 VALUES whose expressions run in Float32, while a value the
+  // caller passes is a Float64 (the reference's own Float32 experiment passes Float64 literals, src/diffprecsions.jl:22) and
+  // promotes its expression; lambda = T(max(lambda, 1e10 / norm_Jtr)) (lm.jl:59) stays a Float32 until the first accepted
+  // step, whose `max(1.0e-8, lambda)` (lm.jl:337, a Float64 literal) makes it a Float64 for the rest of the run; in
+  // LevenbergMarquardt.jl only Float32 operations touch it.  The accept tests multiply by Float64 literals (lm.jl:259,335).
+  using ts::TS;
+  const int W = xf32 ? 32 : 64;
+  auto T_ = [&](double v) { return xf32 ? ts::f32(v) : ts::f64(v); };  // a value of type eltype(x)
+  const TS eps = T_(xf32 ? 1.1920928955078125e-07 : 2.220446049250313e-16), sq = ts::sqrt(eps);
+  const TS cbr = T_(std::pow(eps.v, 1.0 / 3.0));  // eltype(x)(eps^(1/3)): a Float64 power, converted
+  const TS c100 = ts::mul(T_(100), sq), c1000 = ts::mul(T_(1000), sq);
+  auto opt = [&](double given, TS dflt, bool positive) { return (positive ? given > 0 : given >= 0) ? ts::f64(given) : dflt; };
+  const TS restol = opt(o->restol, V ? cbr : c100, false), satol = opt(o->satol, sq, false), srtol = opt(o->srtol, sq, false);
+  const TS oatol = opt(o->oatol, sq, false), ortol = opt(o->ortol, V ? cbr : c1000, false);
+  const TS atol = opt(o->atol, V ? sq : c100, false), rtol = opt(o->rtol, V ? cbr : c1000, false);
+  const TS nu_d = opt(o->nu_d, T_(3), true), nu_m = opt(o->nu_m, T_(3), true), delta_d = opt(o->delta_d, T_(2), true);
+  TS lambda = opt(o->lambda, T_(V ? 30 : 0.1), true);
   const int ite_max = o->ite_max >= 0 ? o->ite_max : (V ? 200 : 100);
   const bool linesearch = V && o->linesearch;
   const bool facto_qr = o->facto >= 1;  // same device solve; the branches differ in the line search's model value only
                                         // (:PCG has no dr vector to recur on either: it re-evaluates like :QR)
+  // norm(v) from the device's sum of squares; 1/2 |v|^2 the way the reference forms it (norm(v)^2 / 2: for a Float32
+  // vector the norm is rounded to Float32 first; for Float64 the sum of squares is halved directly, as before)
+  auto norm_of = [&](double sumsq, int wd) { return wd == 32 ? ts::f32(std::sqrt(sumsq)) : ts::f64(std::sqrt(sumsq)); };
+  auto half_of = [&](double sumsq) {
+    if (!xf32) return ts::f64(0.5 * sumsq);
+    const TS n = ts::f32(std::sqrt(sumsq));
+    return ts::div(ts::mul(n, n), ts::f32(2));
+  };
 
   memset(stats, 0, sizeof *stats);
   stats->status = BA_ST_UNKNOWN;
@@ -843,22 +882,19 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   BA_CHECK(fetch_scalars(p, w, st));
   stats->n_residual++;
   stats->n_jacobian++;
-  double norm_r = std::sqrt(h_sh[SH_RSQ]);
-  double obj = norm_r * norm_r / 2;
-  double norm_Jtr = std::sqrt(h_sh[SH_GP] + h_rp[RP_GC]);
-  double norm_x = std::sqrt(h_sh[SH_X_P] + h_rp[RP_X_C]);
-  if (V) lambda = std::fmax(lambda, 1e10 / norm_Jtr);  // lm.jl:59
-  // eltype(x) = Float32: lambda = T(max(...)) is a Float32 there, and so are nu_d, nu_m (lm.jl:25) -- until the first
-  // accepted step, whose `max(1.0e-8, lambda)` (lm.jl:337, a Float64 literal) promotes it to Float64 for the rest of the
-  // run.  (In LevenbergMarquardt.jl lambda = eltype(x)(0.1) stays Float32 throughout: only Float32 operations touch it.)
-  bool lam_f32 = xf32;
-  auto rl32 = [&](double v) { return lam_f32 ? (double)(float)v : v; };
-  lambda = rl32(lambda);
+  TS norm_r = norm_of(h_sh[SH_RSQ], W);
+  TS obj = ts::div(ts::mul(norm_r, norm_r), T_(2));
+  TS norm_Jtr = norm_of(h_sh[SH_GP] + h_rp[RP_GC], W);
+  TS norm_x = norm_of(h_sh[SH_X_P] + h_rp[RP_X_C], W);
+  if (V) {  // lm.jl:59: lambda = T(max(lambda, 1e10 / norm_Jtr))
+    lambda = ts::max(lambda, ts::div(ts::f64(1e10), norm_Jtr));
+    lambda = T_(lambda.v);
+  }
 
-  double norm_delta = 0, dr2 = 0, ared = 0, pred = 0;
-  const double eps_first = atol + rtol * norm_Jtr;  // lm.jl:107
-  double old_obj = obj;
-  bool small_step = false, first_order = norm_Jtr < eps_first, small_residual = norm_r < restol;
+  TS norm_delta = T_(0), dr2 = T_(0), ared = T_(0), pred = T_(0);
+  const TS eps_first = ts::add(atol, ts::mul(rtol, norm_Jtr));  // lm.jl:107
+  TS old_obj = obj;
+  bool small_step = false, first_order = norm_Jtr.v < eps_first.v, small_residual = norm_r.v < restol.v;
   bool small_obj_change = false, fail2 = false;
   int iter = 0;
   bool tired = iter > ite_max;
@@ -868,8 +904,8 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
 
   while (!(small_step || first_order || small_residual || small_obj_change || tired || fail2)) {
     if (V) iter++;                                                                           // lm.jl:127
-    if (!V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);  // LevenbergMarquardt.jl:143-147
-    if ((rc = trial_step(p, w, lambda, o->normalize, facto_f32, xf32, st)) != BA_OK) break;  // lm.jl:154-254
+    if (!V && cb) cb(cb_ctx, iter, obj.v, ts::sub(old_obj, obj).v, norm_Jtr.v, lambda.v, norm_delta.v, dr2.v, accepted);  // LevenbergMarquardt.jl:143-147
+    if ((rc = trial_step(p, w, lambda.v, o->normalize, facto_f32, xf32, st)) != BA_OK) break;  // lm.jl:154-254
     stats->n_factor++;
     stats->n_residual++;
     if (*w->h_flag == 2) {
@@ -882,72 +918,76 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
       rc = BA_ERR_ZERO_PIVOT;
       break;
     }
-    dr2 = 0.5 * h_sh[SH_MODEL];  // 1/2 |delta_r|^2   (lm.jl:229)
-    double obj_suiv = 0.5 * h_sh[SH_RSQ_TRIAL];
-    double norm_rsuiv = std::sqrt(h_sh[SH_RSQ_TRIAL]);
+    dr2 = half_of(h_sh[SH_MODEL]);  // 1/2 |delta_r|^2   (lm.jl:229)
+    TS obj_suiv = half_of(h_sh[SH_RSQ_TRIAL]);
+    TS norm_rsuiv = norm_of(h_sh[SH_RSQ_TRIAL], W);
     if (!V) iter++;  // LevenbergMarquardt.jl:240
+    // the reference's delta is a Vector{Float32} for a Float32 model -- except under normalize = :A once lambda is a
+    // Float64 (delta /= sqrt(lambda), lm.jl:235-237) or behind a Float64 delta_d in the line search (lm.jl:266)
+    int delta_w = (xf32 && !(V && o->normalize == 2 && lambda.w == 64)) ? 32 : 64;
 
     bool step_accepted;
     int ntimes = 0;
     if (V) {
-      pred = obj - dr2;
-      ared = obj - obj_suiv;
-      step_accepted = ared >= 1e-4 * pred;  // lm.jl:257-259
+      pred = ts::sub(obj, dr2);
+      ared = ts::sub(obj, obj_suiv);
+      step_accepted = ared.v >= 1e-4 * pred.v;  // lm.jl:257-259 (Float64 literal)
       double c_r = w->cr0();  // delta_r = -(J delta + c_r r)   (1; 1/mu in the Float16 branch)
       while (linesearch && !step_accepted && ntimes < 4) {  // lm.jl:264-295
         // delta /= delta_d ; delta_r = (delta_r - r)/delta_d (lm.jl:277): with delta_r = -(J delta + c r) the update is
         // c <- (c + 1)/delta_d, which stays 1 only for the default delta_d = 2 (the reference's comment at lm.jl:275-276
         // assumes it; the code is followed, not the comment)
         // The :QR branch recomputes |J delta + r|^2 instead (lm.jl:273): c stays 1 there.
-        if (!facto_qr) c_r = (c_r + 1.0) / delta_d;
-        if ((rc = launch_scale_scalar(p, w->nvar, w->delta, 1.0 / delta_d, st)) != BA_OK) break;
+        if (!facto_qr) c_r = (c_r + 1.0) / delta_d.v;
+        if (delta_d.w == 64) delta_w = 64;
+        if ((rc = launch_scale_scalar(p, w->nvar, w->delta, 1.0 / delta_d.v, st)) != BA_OK) break;
         if ((rc = step_scalars(p, w, st, c_r)) != BA_OK) break;
         if ((rc = trial_point(p, w, st, xf32)) != BA_OK) break;
         stats->n_residual++;
         if ((rc = comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st)) != BA_OK) break;
         if ((rc = fetch_scalars(p, w, st)) != BA_OK) break;
-        dr2 = 0.5 * h_sh[SH_MODEL];
-        obj_suiv = 0.5 * h_sh[SH_RSQ_TRIAL];
-        norm_rsuiv = std::sqrt(h_sh[SH_RSQ_TRIAL]);
-        pred = obj - dr2;
-        ared = obj - obj_suiv;
-        step_accepted = ared >= 1e-4 * pred;
+        dr2 = half_of(h_sh[SH_MODEL]);
+        obj_suiv = half_of(h_sh[SH_RSQ_TRIAL]);
+        norm_rsuiv = norm_of(h_sh[SH_RSQ_TRIAL], W);
+        pred = ts::sub(obj, dr2);
+        ared = ts::sub(obj, obj_suiv);
+        step_accepted = ared.v >= 1e-4 * pred.v;
         ntimes++;
       }
       if (rc != BA_OK) break;
     } else {
-      step_accepted = (obj_suiv - obj) < 1e-4 * (dr2 - obj);  // LevenbergMarquardt.jl:243
+      step_accepted = ts::sub(obj_suiv, obj).v < 1e-4 * ts::sub(dr2, obj).v;  // LevenbergMarquardt.jl:243
     }
     accepted = step_accepted;
-    const double nd = std::sqrt(h_sh[SH_DELTA_P] + h_rp[RP_DELTA_C]);
+    const TS nd = norm_of(h_sh[SH_DELTA_P] + h_rp[RP_DELTA_C], delta_w);
 
     if (V) {
       norm_delta = nd;  // lm.jl:297-302
-      if (std::isnan(norm_delta)) {
+      if (std::isnan(norm_delta.v)) {
         fail2 = true;
         continue;
       }
-      if (cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, ared / pred,
-                 (step_accepted && dr2 <= obj) ? 1 : 0);  // lm.jl:304
+      const double rho = ts::div(ared, pred).v;
+      if (cb) cb(cb_ctx, iter, obj.v, ts::sub(old_obj, obj).v, norm_Jtr.v, lambda.v, norm_delta.v, rho,
+                 (step_accepted && dr2.v <= obj.v) ? 1 : 0);  // lm.jl:304
       if (o->verbose)
-        fprintf(stderr, "%6d %14.7e %10.2e %10.2e %10.2e %10.2e %10.2e %s\n", iter, obj, old_obj - obj, norm_Jtr, lambda,
-                norm_delta, ared / pred, (step_accepted && dr2 <= obj) ? "acc" : "rej");
+        fprintf(stderr, "%6d %14.7e %10.2e %10.2e %10.2e %10.2e %10.2e %s\n", iter, obj.v, ts::sub(old_obj, obj).v, norm_Jtr.v,
+                lambda.v, norm_delta.v, rho, (step_accepted && dr2.v <= obj.v) ? "acc" : "rej");
     }
 
     if (!step_accepted) {
       stats->n_rejected++;
-      if (V) lambda = rl32(rl32(std::fmax(lambda, rl32(1 / norm_delta))) * rl32(std::pow(nu_m, (double)(ntimes + 1))));  // lm.jl:308
-      else lambda = rl32(lambda * nu_m);                                                            // LevenbergMarquardt.jl:269
+      if (V) lambda = ts::mul(ts::max(lambda, ts::div(norm_delta.w == 32 ? ts::f32(1) : ts::f64(1), norm_delta)), ts::powi(nu_m, ntimes + 1));  // lm.jl:308
+      else lambda = ts::mul(lambda, nu_m);                                                            // LevenbergMarquardt.jl:269
     } else {
       stats->n_accepted++;
       if (V) {  // lm.jl:329-337
-        if (ntimes > 0) lambda = rl32(lambda / rl32(std::pow(nu_d, (double)(ntimes - 1))));
-        else lambda = rl32(lambda / nu_d);
-        if (ared >= 0.9 * pred) lambda = rl32(lambda / nu_d);
-        lambda = std::fmax(1.0e-8, lambda);
-        lam_f32 = false;  // promoted by the Float64 literal
+        if (ntimes > 0) lambda = ts::div(lambda, ts::powi(nu_d, ntimes - 1));
+        else lambda = ts::div(lambda, nu_d);
+        if (ared.v >= 0.9 * pred.v) lambda = ts::div(lambda, nu_d);
+        lambda = ts::max(ts::f64(1.0e-8), lambda);  // the Float64 literal promotes lambda for the rest of the run
       } else {
-        lambda = rl32(lambda / nu_d);  // LevenbergMarquardt.jl:292
+        lambda = ts::div(lambda, nu_d);  // LevenbergMarquardt.jl:292
       }
       std::swap(w->x, w->x_trial);  // x .= x_suiv
       std::swap(w->r, w->r_trial);  // r .= r_suiv
@@ -957,20 +997,20 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
       obj = obj_suiv;
       if ((rc = accept_refresh(p, w, xf32, st)) != BA_OK) break;  // J, J'r  (lm.jl:341,370)
       stats->n_jacobian++;
-      norm_Jtr = std::sqrt(h_sh[SH_GP] + h_rp[RP_GC]);
-      norm_x = std::sqrt(h_sh[SH_X_P] + h_rp[RP_X_C]);
+      norm_Jtr = norm_of(h_sh[SH_GP] + h_rp[RP_GC], W);
+      norm_x = norm_of(h_sh[SH_X_P] + h_rp[RP_X_C], W);
       if (!V) norm_delta = nd;  // LevenbergMarquardt.jl:352
-      small_step = norm_delta < satol + srtol * norm_x;  // lm.jl:375-379
-      first_order = norm_Jtr < eps_first;
-      small_residual = norm_r < restol;
-      small_obj_change = (old_obj - obj) < oatol + ortol * old_obj;
+      small_step = norm_delta.v < ts::add(satol, ts::mul(srtol, norm_x)).v;  // lm.jl:375-379
+      first_order = norm_Jtr.v < eps_first.v;
+      small_residual = norm_r.v < restol.v;
+      small_obj_change = ts::sub(old_obj, obj).v < ts::add(oatol, ts::mul(ortol, old_obj)).v;
     }
     if (!V && o->verbose)
-      fprintf(stderr, "%6d %14.7e %10.2e %10.2e %10.2e %10.2e %10.2e %s\n", iter, obj, old_obj - obj, norm_Jtr, lambda, nd,
-              dr2, step_accepted ? "true" : "false");
+      fprintf(stderr, "%6d %14.7e %10.2e %10.2e %10.2e %10.2e %10.2e %s\n", iter, obj.v, ts::sub(old_obj, obj).v, norm_Jtr.v,
+              lambda.v, nd.v, dr2.v, step_accepted ? "true" : "false");
     tired = iter > ite_max;  // lm.jl:382
   }
-  if (rc == BA_OK && !V && cb) cb(cb_ctx, iter, obj, old_obj - obj, norm_Jtr, lambda, norm_delta, dr2, accepted);
+  if (rc == BA_OK && !V && cb) cb(cb_ctx, iter, obj.v, ts::sub(old_obj, obj).v, norm_Jtr.v, lambda.v, norm_delta.v, dr2.v, accepted);
   stats->loop_s = wall() - t_loop;
 
   if (rc != BA_OK) {
@@ -982,9 +1022,9 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   else if (fail2) stats->status = BA_ST_EXCEPTION;
   else if (tired) stats->status = BA_ST_MAX_ITER;
   stats->iter = iter;
-  stats->objective = obj;
-  stats->dual_feas = norm_Jtr;
-  stats->lambda_final = lambda;
+  stats->objective = obj.v;
+  stats->dual_feas = norm_Jtr.v;
+  stats->lambda_final = lambda.v;
   stats->n_cg = (int)w->n_cg;
   w->pcg = false;
   {

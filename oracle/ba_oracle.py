@@ -76,6 +76,9 @@ def lib():
     L.orc_lm_solve.argtypes = [C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f64p, f64p, C.POINTER(LMOpts),
                                C.POINTER(LMStats), C.c_void_p, C.c_int]
     L.orc_lm_solve.restype = C.c_int
+    L.orc_lm_solve_f32.argtypes = [C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f32p, f32p, C.POINTER(LMOpts),
+                                   C.POINTER(LMStats), C.c_void_p, C.c_int]
+    L.orc_lm_solve_f32.restype = C.c_int
     L.orc_lm_step.argtypes = [C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f64p, f64p, C.c_double, f64p,
                               C.c_void_p, C.c_void_p]
     L.orc_lm_step.restype = C.c_int
@@ -202,4 +205,25 @@ def lm_solve(ncams, npnts, cam_idx1, pnt_idx1, pt2d, x0, variant=1, normalize=0,
     log = np.zeros((log_cap, 8))
     rc = lib().orc_lm_solve(ncams, npnts, nobs, _i64(cam_idx1), _i64(pnt_idx1), _f64(pt2d), x, C.byref(o),
                             C.byref(st), log.ctypes.data_as(C.c_void_p), log_cap)
+    return rc, x, st, log[: st.n_log]
+
+
+def lm_solve_f32(ncams, npnts, cam_idx1, pnt_idx1, pt2d, x0, variant=1, normalize=0, linesearch=False, ite_max=-1, lam=-1.0,
+                 max_iter_timed=0, log_cap=512, **tols):
+    """Levenberg_Marquardt on a Float32 model (eltype(x) = Float32, facto_type = Float32 = its default): every scalar with
+    the width Julia's promotion rules give it (oracle/ba_oracle.c, orc_lm_solve_f32).  Tolerances / parameters passed here
+    are Float64 values, as literals are in the reference's own call (src/diffprecsions.jl:22); omitted ones are the
+    eps(Float32)-derived Float32 defaults."""
+    nobs = len(cam_idx1)
+    o = LMOpts(variant=variant, normalize=normalize, linesearch=int(linesearch), facto_f32=1,
+               ite_max=ite_max, restol=tols.get("restol", -1.0), satol=tols.get("satol", -1.0),
+               srtol=tols.get("srtol", -1.0), oatol=tols.get("oatol", -1.0), ortol=tols.get("ortol", -1.0),
+               atol=tols.get("atol", -1.0), rtol=tols.get("rtol", -1.0), nu_d=tols.get("nu_d", -1.0),
+               nu_m=tols.get("nu_m", -1.0), lam=lam, delta_d=tols.get("delta_d", -1.0), facto_time_cap_s=0.0,
+               max_iter_timed=max_iter_timed, facto_qr=0)
+    st = LMStats()
+    x = np.ascontiguousarray(x0, dtype=np.float32).copy()
+    log = np.zeros((log_cap, 8))
+    rc = lib().orc_lm_solve_f32(ncams, npnts, nobs, _i64(cam_idx1), _i64(pnt_idx1), np.ascontiguousarray(pt2d, dtype=np.float32),
+                                x, C.byref(o), C.byref(st), log.ctypes.data_as(C.c_void_p), log_cap)
     return rc, x, st, log[: st.n_log]

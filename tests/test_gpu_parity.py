@@ -481,35 +481,92 @@ def test_lm_facto_f16_and_two_stage_restart(ba, orc, small_prob, gpu_ok):
     m.close()
 
 
-def test_lm_float32_model(ba, small_prob, gpu_ok):
+def _float32_rows(st, log_ref, tag, f_rtol=2e-5, lam_rtol=1e-6, delta_rtol=2e-3):
+    """Row-by-row comparison of a Float32-model run with the oracle's T = Float32 loop: accept / reject sequence equal,
+    lambda to 1e-6 wherever it comes from the discrete updates (a rejected step's max(lambda, 1/|delta|) carries |delta|:
+    delta_rtol there), f and |J'r| to Float32 level, |delta| to the accuracy of a Float32 factorisation."""
+    log = np.array([r[:7] + (float(r[7]),) for r in st.log])
+    n = min(len(log), len(log_ref))
+    assert len(log) == len(log_ref), f"{tag}: {len(log)} log rows, oracle {len(log_ref)}"
+    acc, acc_ref = [bool(v) for v in log[:n, 7]], [bool(v) for v in log_ref[:n, 7]]
+    assert acc == acc_ref, f"{tag}: accept/reject sequence {acc} vs oracle {acc_ref}"
+    for col, name, rtol in ((1, "f", f_rtol), (3, "|J'r|", 2e-3), (5, "|delta|", delta_rtol)):
+        err = np.abs(log[:n, col] - log_ref[:n, col]) / np.abs(log_ref[:n, col])
+        k = int(np.argmax(err))
+        assert err[k] <= rtol, f"{tag}: {name} row {k}: {log[k, col]!r} vs oracle {log_ref[k, col]!r} (relative {err[k]:.2e} > {rtol:g})"
+    for k in range(n):
+        after_reject = k > 0 and not acc_ref[k - 1]
+        rtol = delta_rtol if after_reject else lam_rtol
+        e = abs(log[k, 4] - log_ref[k, 4]) / log_ref[k, 4]
+        assert e <= rtol, f"{tag}: lambda row {k}: {log[k, 4]!r} vs oracle {log_ref[k, 4]!r} (relative {e:.2e} > {rtol:g})"
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("norm,code", [("None", 0), ("J", 1)])
+def test_lm_float32_model(ba, orc, small_prob, gpu_ok, variant, norm, code):
     """BALNLPModel(file, Float32) through Levenberg_Marquardt (eltype(x) = Float32, facto_type defaults to Float32,
-    eps(Float32) tolerances -- lm.jl:20-26).  No reference fixture pins a Float32 run (parity unpinned); checked here:
-    Float32 iterates, and the same minimum as the Float64 run to Float32-level accuracy."""
+    src/lm.jl:20-26; the reference's own Float32 experiment and its tolerances: src/diffprecsions.jl:19-24) against the
+    oracle's T = Float32 loop (oracle/ba_oracle.c orc_lm_solve_f32: every scalar with the width Julia's promotion rules give
+    it -- Float32 norms, obj, pred, ared; lambda a Float32 until lm.jl:337's Float64 literal promotes it; Float64 accept
+    tests).  What differs by construction: the reference factors the AUGMENTED system in Float32, the device eliminates
+    residual rows and points in Float64 and factors the reduced camera system in Float32 -- steps agree to Float32-solve
+    accuracy, not to the bit.  No reference fixture pins a Float32 run: parity unpinned beyond the oracle."""
     p = small_prob
     arrays = list(ba.synthetic.as_arrays(p))
     arrays32 = [arrays[0], arrays[1], arrays[2].astype(np.float32), arrays[3].astype(np.float32)] + arrays[4:]
     m32 = ba.BALNLPModel(arrays=tuple(arrays32), T=np.float32)
-    m64 = ba.BALNLPModel(arrays=tuple(arrays))
-    # tolerances of the reference's own Float32 experiment (src/diffprecsions.jl:22): with the eps(Float32)-derived
-    # defaults the step test satol + srtol |x| = 3.5e-4 (1 + |x|) stops a BAL problem (|x| ~ 1e4) at the first accepted step
-    tol32 = dict(oatol=1e-4, ortol=1e-4, atol=1e-4, rtol=1e-5, satol=1e-6, srtol=1e-7)
-    st_def = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), "LDL", "AMD", "None", False)
-    assert st_def.status == "small_step" and st_def.iter <= 2
-    st32 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), "LDL", "AMD", "None", False, **tol32)
-    st64 = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m64), "LDL", "AMD", "None", False)
-    print("T=Float32:", st32.status, st32.iter, st32.objective, " T=Float64:", st64.status, st64.iter, st64.objective)
-    assert st32.solution.dtype == np.float32
-    assert st32.status in ("first_order", "small_residual", "acceptable", "small_step")
-    assert abs(st32.objective - st64.objective) <= 2e-3 * st64.objective
+    tol32 = dict(oatol=1e-4, ortol=1e-4, atol=1e-4, rtol=1e-5, satol=1e-6, srtol=1e-7)  # src/diffprecsions.jl:22
+    args = ("LDL", "AMD", norm) + ((False,) if variant else ())
+    st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), *args, **tol32)
+    rc, x_ref, st_ref, log_ref = orc.lm_solve_f32(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], arrays32[2], arrays32[3],
+                                                   variant=variant, normalize=code, **tol32)
+    tag = f"variant {variant}, normalize {norm}"
+    print(tag, "device:", st.status, st.iter, st.objective, " oracle:", orc.STATUS[st_ref.status], st_ref.iter, st_ref.objective)
+    assert rc == 0
+    assert st.solution.dtype == np.float32
+    assert st.iter == st_ref.iter, f"{tag}: {st.iter} iterations, oracle {st_ref.iter}"
+    assert st.status == orc.STATUS[st_ref.status], f"{tag}: status {st.status}, oracle {orc.STATUS[st_ref.status]}"
+    _float32_rows(st, log_ref, tag, f_rtol=1e-4 if variant else 1e-3)
+    assert abs(st.objective - st_ref.objective) <= (1e-4 if variant else 1e-3) * st_ref.objective, f"{tag}: objective {st.objective!r} vs {st_ref.objective!r}"
+    assert abs(st.lambda_final - st_ref.lambda_final) <= 1e-6 * st_ref.lambda_final, f"{tag}: final lambda {st.lambda_final!r} vs {st_ref.lambda_final!r}"
     # the returned objective is the one of the returned (Float32) point, evaluated by the Float32 residual kernel
-    r = m32.cons(st32.solution)
-    assert abs(0.5 * float(r.astype(np.float64) @ r.astype(np.float64)) - st32.objective) <= 1e-5 * st32.objective
-    st32b = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), "LDL", "AMD", "None", **tol32)  # LevenbergMarquardt.jl variant
-    print("old variant, T=Float32:", st32b.status, st32b.iter, st32b.objective)
-    st64b = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m64), "LDL", "AMD", "None", **tol32)
-    assert abs(st32b.objective - st64b.objective) <= 2e-3 * st64b.objective
+    r = m32.cons(st.solution)
+    assert abs(0.5 * float(r.astype(np.float64) @ r.astype(np.float64)) - st.objective) <= 1e-5 * st.objective
+    if variant == 1 and code == 0:
+        # eps(Float32)-derived default tolerances: satol + srtol |x| stops a BAL problem at its first accepted step, in
+        # the oracle as on the device
+        st_def = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), "LDL", "AMD", "None", False)
+        rc, _, sd_ref, _ = orc.lm_solve_f32(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], arrays32[2], arrays32[3], variant=1)
+        assert rc == 0 and st_def.status == orc.STATUS[sd_ref.status] == "small_step" and st_def.iter == sd_ref.iter
     m32.close()
-    m64.close()
+
+
+def test_lm_float32_model_rejections(ba, orc, small_prob, gpu_ok):
+    """The Float32-model loop through rejected steps and the line search (far start, small initial damping): lambda goes
+    through max(lambda, 1 / |delta|) * nu_m^(ntimes + 1) in Float32 before the first accepted step and in Float64 after."""
+    p = small_prob
+    x0 = _hard_start(p).astype(np.float32)
+    arrays = list(ba.synthetic.as_arrays(p))
+    arrays32 = [arrays[0], arrays[1], arrays[2].astype(np.float32), x0] + arrays[4:]
+    m32 = ba.BALNLPModel(arrays=tuple(arrays32), T=np.float32)
+    tol32 = dict(oatol=1e-4, ortol=1e-4, atol=1e-4, rtol=1e-5, satol=1e-6, srtol=1e-7)
+    for ls in (False, True):
+        st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m32), "LDL", "AMD", "None", ls, lam=1e-3, ite_max=12, **tol32)
+        rc, _, st_ref, log_ref = orc.lm_solve_f32(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], arrays32[2], x0, variant=1,
+                                                  linesearch=ls, lam=1e-3, ite_max=12, **tol32)
+        assert rc == 0
+        n = _well_conditioned_prefix(log_ref)
+        log = np.array([r[:7] + (float(r[7]),) for r in st.log])
+        print(f"linesearch={ls}: device {st.status} {st.iter} {st.objective}; oracle {orc.STATUS[st_ref.status]} {st_ref.iter} "
+              f"{st_ref.objective}; rows compared {n}; rejected rows {int(np.sum(log_ref[:n, 7] == 0))}")
+        assert n >= 3 and np.any(log_ref[:n, 7] == 0), "the start must produce rejected steps inside the compared prefix"
+        acc, acc_ref = [bool(v) for v in log[:n, 7]], [bool(v) for v in log_ref[:n, 7]]
+        assert acc == acc_ref, f"linesearch={ls}: accept/reject {acc} vs oracle {acc_ref}"
+        err_f = np.abs(log[:n, 1] - log_ref[:n, 1]) / np.abs(log_ref[:n, 1])
+        err_l = np.abs(log[:n, 4] - log_ref[:n, 4]) / np.abs(log_ref[:n, 4])
+        assert err_f.max() <= 1e-4, f"linesearch={ls}: f differs by {err_f.max():.2e} at row {int(err_f.argmax())}"
+        assert err_l.max() <= 5e-3, f"linesearch={ls}: lambda differs by {err_l.max():.2e} at row {int(err_l.argmax())}"
+    m32.close()
 
 
 def test_lm_linesearch_vs_oracle(ba, orc, small_prob, gpu_ok):

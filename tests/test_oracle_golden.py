@@ -245,3 +245,32 @@ def test_oracle_qr_branch_equals_ldl_branch(orc, ba):
         assert out[0][:2] == out[1][:2]
         assert abs(out[0][2] - out[1][2]) <= 1e-10 * out[0][2]
         assert np.allclose(out[0][3], out[1][3], rtol=1e-8)
+
+
+def test_oracle_float32_model_loop(ba, orc):
+    """orc_lm_solve_f32 (T = Float32, src/lm.jl:15-59,251-337 with eltype(x) = Float32): self-consistency of the restatement --
+    with the reference's Float32-experiment tolerances (src/diffprecsions.jl:22) it follows the Float64 loop's accept/reject
+    sequence and reaches its minimum to Float32 level; with the eps(Float32)-derived defaults the step test stops it at the
+    first accepted step; lambda is a Float32 value before the first accepted step and not afterwards (lm.jl:337)."""
+    p = ba.synthetic.make_problem(12, 400, 1800, seed=11)
+    a = (p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"])
+    pt32, x32 = p["pt2d"].astype(np.float32), p["x0"].astype(np.float32)
+    tol32 = dict(oatol=1e-4, ortol=1e-4, atol=1e-4, rtol=1e-5, satol=1e-6, srtol=1e-7)
+    for variant in (1, 0):
+        for norm in (0, 1, 2):
+            rc, x, st, log = orc.lm_solve_f32(*a, pt32, x32, variant=variant, normalize=norm, **tol32)
+            rc64, x64, st64, log64 = orc.lm_solve(*a, p["pt2d"], p["x0"], variant=variant, normalize=norm)
+            assert rc == 0 and rc64 == 0 and x.dtype == np.float32
+            assert abs(st.objective - st64.objective) <= 1e-5 * st64.objective, (variant, norm, st.objective, st64.objective)
+            n = min(len(log), len(log64), 6)
+            assert list(log[:n, 7]) == list(log64[:n, 7])
+            assert np.allclose(log[:n, 1], log64[:n, 1], rtol=1e-3)  # (a Float32 LDL' of the augmented system: steps to ~1e-4)
+    rc, x, st, log = orc.lm_solve_f32(*a, pt32, x32, variant=1)
+    assert rc == 0 and orc.STATUS[st.status] == "small_step" and st.iter <= 2
+    rc, x, st, log = orc.lm_solve_f32(*a, pt32, x32, variant=1, **tol32)
+    lam = log[:, 4]
+    assert lam[0] == np.float32(lam[0]) and lam[1] == np.float32(lam[1]) / 1 and np.float64(np.float32(lam[1])) == lam[1]
+    assert any(np.float64(np.float32(v)) != v for v in lam[2:]), "lambda must become a Float64 after the first accepted step"
+    # the old variant keeps lambda in Float32 throughout (LevenbergMarquardt.jl:269,292)
+    rc, x, st, log = orc.lm_solve_f32(*a, pt32, x32, variant=0, **tol32)
+    assert all(np.float64(np.float32(v)) == v for v in log[:, 4])
