@@ -181,3 +181,30 @@ def test_rccl_single_rank(ba, small_prob, gpu_ok):
     finally:
         dist.destroy_process_group()
     ref.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_launch_path(gpu_ok):
+    """`python bench.py --gpus 2` exactly as the driver starts an N > 1 run when no launcher is around it: the parent spawns
+    its ranks (torch.distributed.run, 127.0.0.1) BEFORE anything touches the GPU, the ranks shard the problem, one JSON line
+    comes back from rank 0.  Two gloo ranks on the one GPU of this box (--single-device --backend gloo), a scaled-down Venice
+    shape; the objective after the fixed iterations equals the one-rank run's."""
+    def run(extra):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "0.05", "--steps", "3", "--warmup", "1",
+               "--cpu-seconds", "0", "--cpu-full", "none", "--no-pcg"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, f"bench.py {' '.join(extra)} failed:\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}"
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}: {r.stdout[-1500:]}"
+        return json.loads(lines[0])
+
+    one = run([])
+    two = run(["--gpus", "2", "--single-device", "--backend", "gloo"])
+    assert one["n_gpus"] == 1 and "comm" not in one
+    assert two["n_gpus"] == 2 and two["steps"] == 3 and two["warmup"] == 1 and two["scaling"] == "strong"
+    assert two["value"] > 0 and abs(two["value"] * two["ms_per_step"] - 1e3) < 1e-6 * 1e3
+    assert "comm" in two and two["comm"]["calls"] > 0 and two["comm"]["bytes"] > 0, two.get("comm")
+    assert two["roofline"]["frac"] > 0 and two["cpu_baseline"] is None
+    f1, f2 = one["lm"]["objective"], two["lm"]["objective"]
+    assert abs(f2 - f1) <= 1e-9 * f1, f"objective after 3 iterations: 2 ranks {f2!r} vs 1 rank {f1!r}"
