@@ -462,7 +462,9 @@ constexpr size_t GEMM_PRIV_LDS_ELEMS = gemm_priv_lds_bytes<double>() / sizeof(do
 template <typename T, int NP>
 __device__ inline void tile_gemm_abt_priv(const T *__restrict__ A0, const T *__restrict__ B0,
                                           const T *__restrict__ A1, const T *__restrict__ B1, T *lds,
-                                          typename RT<T>::v4 acc[4][4]) {
+                                          typename RT<T>::v4 acc[4][4], const T *__restrict__ A2 = nullptr,
+                                          const T *__restrict__ B2 = nullptr, const T *__restrict__ A3 = nullptr,
+                                          const T *__restrict__ B3 = nullptr) {
   typedef typename PV<T>::vu vu;
   constexpr int PKC = PV<T>::KC, PLDK = PV<T>::LDK, VL = PV<T>::VL;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -493,8 +495,9 @@ __device__ inline void tile_gemm_abt_priv(const T *__restrict__ A0, const T *__r
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nx = ch + 1;
     if (nx < NCH) {
-      const T *A = ((NP == 2 && nx >= NB / PKC) ? A1 : A0) + wr * NB;
-      const T *B = ((NP == 2 && nx >= NB / PKC) ? B1 : B0) + wc * NB;
+      const int pn = nx / (NB / PKC);  // panel of the next chunk (NP = 4: the K = 512 pass of the quad-update probe)
+      const T *A = (pn == 0 ? A0 : pn == 1 ? A1 : pn == 2 ? A2 : A3) + wr * NB;
+      const T *B = (pn == 0 ? B0 : pn == 1 ? B1 : pn == 2 ? B2 : B3) + wc * NB;
       const int k0 = (nx & (NB / PKC - 1)) * PKC;
 #pragma unroll
       for (int it = 0; it < NLD; it++) {
@@ -1051,6 +1054,10 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
   if constexpr ((DBG & 16) != 0 && sizeof(T) == 8)
     tile_gemm_abt_dma(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
                       S + tix(co, jo, k + 1) * NB * NB, lds, acc);
+  else if constexpr ((DBG & 32) != 0)  // K = 512 probe (tools/bench_update.py variant 32): panels k .. k+3, V2 / V3 behind V1
+    tile_gemm_abt_priv<T, 4>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                          S + tix(co, jo, k + 1) * NB * NB, lds, acc, V1 + (int64_t)(nt + io) * NB * NB,
+                          S + tix(co, jo, k + 2) * NB * NB, V1 + (int64_t)(2 * nt + io) * NB * NB, S + tix(co, jo, k + 3) * NB * NB);
   else if (!(DBG & 8))
     tile_gemm_abt_priv<T, 2>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
                           S + tix(co, jo, k + 1) * NB * NB, lds, acc);

@@ -33,6 +33,10 @@ static int set_bench_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 17>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 32>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 33>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 9>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
   return BA_OK;
@@ -44,14 +48,17 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   const size_t tiles = (size_t)nt * (nt + 1) / 2 * NB * NB;
   double *S = nullptr, *V = nullptr;
   BA_HIP_CHECK(hipMalloc((void **)&S, tiles * sizeof(double)));
-  BA_HIP_CHECK(hipMalloc((void **)&V, (size_t)2 * nt * NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMalloc((void **)&V, (size_t)4 * nt * NB * NB * sizeof(double)));
   BA_HIP_CHECK(hipMemset(S, 0, tiles * sizeof(double)));
-  BA_HIP_CHECK(hipMemset(V, 0, (size_t)2 * nt * NB * NB * sizeof(double)));
+  BA_HIP_CHECK(hipMemset(V, 0, (size_t)4 * nt * NB * NB * sizeof(double)));
   if (getenv("BA_BENCH_NONZERO")) {  // operands with real bit patterns (power / clocks differ from all-zero data)
     hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, 0, S, tiles, 1e-3);
-    hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)(((size_t)2 * nt * NB * NB + 255) / 256)), dim3(256), 0, 0, V, (size_t)2 * nt * NB * NB, 1e-3);
+    const double sc = getenv("BA_BENCH_ENTROPY") ? -1e-3 : 1e-3;  // negative: full-entropy mantissas
+    hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, 0, S, tiles, sc);
+    hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)(((size_t)4 * nt * NB * NB + 255) / 256)), dim3(256), 0, 0, V, (size_t)4 * nt * NB * NB, sc);
   }
-  const int m = nt - 2, nblk = m * (m + 1) / 2, grid = ((nblk + 7) / 8) * 8;
+  const bool quad = (variant & 32) != 0;  // K = 512: panels 0 .. 3, trailing matrix from tile column 4
+  const int m = nt - (quad ? 4 : 2), nblk = m * (m + 1) / 2, grid = ((nblk + 7) / 8) * 8;
   std::vector<int64_t> h_co;
   dense_ldl_layout(nt, 1, &h_co, nullptr);
   int64_t *co = nullptr;
@@ -68,6 +75,8 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
       case 8: hipLaunchKernelGGL((k_ldl_update<double, 1, 8>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       case 16: hipLaunchKernelGGL((k_ldl_update<double, 1, 16>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       case 17: hipLaunchKernelGGL((k_ldl_update<double, 1, 17>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 32: hipLaunchKernelGGL((k_ldl_update<double, 1, 32>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
+      case 33: hipLaunchKernelGGL((k_ldl_update<double, 1, 33>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
       case 9: hipLaunchKernelGGL((k_ldl_update<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       default: hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr);
     }

@@ -7,9 +7,9 @@ import _benchlib
 ba, L = _benchlib.load()
 nt = int(sys.argv[1]) if len(sys.argv) > 1 else 126
 L.ba_debug_update_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
-m = nt - 2
-flops = m * (m + 1) / 2 * 2 * 128 * 128 * 256
 for v in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 1, 2, 8, 9, 16, 17, 0, 16)):
+    m = nt - (4 if v & 32 else 2)  # variants 32 / 33: K = 512 (four panels per pass; 33: store-only epilogue)
+    flops = m * (m + 1) / 2 * 2 * 128 * 128 * (512 if v & 32 else 256)
     ms = C.c_double(0)
     rc = L.ba_debug_update_bench(nt, v, int(os.environ.get('BA_BENCH_REPS', '5')), C.byref(ms))
     print(f"variant {v}: {ms.value:.3f} ms  {flops / ms.value / 1e9:.1f} TFLOP/s (rc {rc})", flush=True)
