@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="venice-1778")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only; invalid as a result)")
+    ap.add_argument("--locality", type=float, default=None,
+                    help="cameras of a point drawn from a window of this fraction of the cameras: block-banded reduced camera "
+                         "matrix (synthetic.make_problem); default: every camera pair shares points, dense S")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-full", default="dubrovnik-356",
@@ -131,7 +134,7 @@ def main():
 
     # ---- workload ---------------------------------------------------------------------------------------------------
     t0 = time.time()
-    prob = ba.synthetic.make_named(args.workload, scale=args.scale)
+    prob = ba.synthetic.make_named(args.workload, scale=args.scale, locality=args.locality)
     arrays = ba.synthetic.as_arrays(prob)
     if world > 1:
         arrays, info = ba.parallel.shard_problem(arrays, rank, world)
@@ -349,6 +352,7 @@ def main():
             "config": {"workload": f"{args.workload} shape: ncams={ncams} npnts={npnts_g} nobs={nobs_g}, seed "
                                    f"{ba.synthetic.BASE_SEED}, lm.jl variant, {FACTO}/None" + (f" (pcg_tol {PCG_TOL:g})" if FACTO == "PCG" else "") + f", facto_type {args.facto_type}, fixed {args.steps} iterations"
                                    + ("" if args.scale == 1.0 else f" SCALED x{args.scale} (debug)")
+                                   + ("" if args.locality is None else f" LOCALITY {args.locality} (block-banded S; not the headline configuration)")
                                    + (f" EMULATED SHARD {args.emulate_shard} (one rank's compute, no communicator)" if args.emulate_shard else ""),
                        "parallelism": f"points sharded over {world} rank(s), cameras replicated"
                                       + ("" if world == 1 else "; reduced camera matrix reduced onto the owners of its tile column "
@@ -366,6 +370,9 @@ def main():
             "kernel_ms": {k: round(v[0], 3) for k, v in prof.items() if v[1] > 0},
             "setup_s": t_setup,
         }
+        if FACTO != "PCG":
+            tf, ff, sp = ba.schur_pattern(nlp)
+            out["schur_pattern"] = {"tile_fill": tf, "update_tiles_over_dense": ff, "list_schedule": sp}
         if reducer is not None:
             out["comm"] = {"transport": "rccl (called from the library)" if args.backend == "nccl" else "hook over " + args.backend,
                            "calls": reducer.calls, "bytes": reducer.bytes,

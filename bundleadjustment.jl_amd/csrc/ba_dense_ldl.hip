@@ -648,12 +648,14 @@ __device__ inline void tile_gemm_rows(const T *__restrict__ A, const T *__restri
 template <typename T, bool FWD>
 __global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv_k,
                                                       const T *__restrict__ D_k, T *__restrict__ V, int k,
-                                                      T *__restrict__ b, T *__restrict__ y) {
+                                                      T *__restrict__ b, T *__restrict__ y,
+                                                      const int *__restrict__ rows = nullptr) {
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
   T *sA = lds, *sB = lds + 2 * RS * LDK, *ysh = lds + 2 * (RS + NB) * LDK, *red = ysh + NB;  // red: 4 x 32
-  const int i = k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
+  // rows (block-sparse S): the tile rows of this panel's pattern, ascending; null: every tile row below the diagonal tile
+  const int i = rows ? rows[blockIdx.x >> 2] : k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
   T *Sik = S + tix(co, i, k) * NB * NB + r0 * NB;
   T *Vi = V + (int64_t)i * NB * NB + r0 * NB;
   typename RT<T>::v4 acc[2][2];
@@ -711,12 +713,13 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const in
 
 // rows [32 rq, 32 rq + 32) of S_{i,k+1} -= V0_i L_{k+1,k}'   (grid = 4 (nt-k-1))
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, int k) {
+__global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, int k,
+                                                     const int *__restrict__ rows = nullptr) {
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
   T *sA = lds, *sB = lds + 2 * RS * LDK;
-  const int i = k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
+  const int i = rows ? rows[blockIdx.x >> 2] : k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
   typename RT<T>::v4 acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; m++)
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
                                                         int nblk, int *__restrict__ ready,
                                                         const int *__restrict__ own_cols = nullptr,
                                                         const int64_t *__restrict__ own_pref = nullptr, int m0 = 0,
-                                                        int m_end = 0, int ready_tiles = 1) {
+                                                        int m_end = 0, int ready_tiles = 1, const int *__restrict__ rows = nullptr) {
   BA_VT
   static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -1040,8 +1043,9 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
       while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
       while (ii * (ii + 1) / 2 > t) ii--;
       const int jj = t - ii * (ii + 1) / 2;
-      i = base + ii;
-      j = base + jj;
+      // rows (block-sparse S): the pair's pattern, ascending -- tile (rows[ii], rows[jj]) instead of (base + ii, base + jj)
+      i = rows ? rows[ii] : base + ii;
+      j = rows ? rows[jj] : base + jj;
     }
   }
   T *Sij = S + tix(co, i, j) * NB * NB;
@@ -1136,7 +1140,7 @@ __device__ inline T wsum(T v) {
 // forward step k: y_k = Linv_k b_k (every workgroup recomputes it; block 0 stores it), then b_i -= L_ik y_k, i > k.
 template <typename T>
 __global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
-                                                   T *__restrict__ b, T *__restrict__ y, int k) {
+                                                   T *__restrict__ b, T *__restrict__ y, int k, const int *__restrict__ rows = nullptr) {
   BA_VT
   __shared__ T yk[NB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1153,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const
     if (tid < NB) y[(int64_t)k * NB + tid] = yk[tid];
     return;
   }
-  const int i = k + blockIdx.x;
+  const int i = rows ? rows[blockIdx.x - 1] : k + blockIdx.x;
   const T *Lik = S + tix(co, i, k) * NB * NB;
   const T y0 = yk[2 * lane], y1 = yk[2 * lane + 1];
   for (int rr = 0; rr < 32; rr++) {
@@ -1169,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const
 template <typename T>
 __global__ __launch_bounds__(256) void k_bwd_step(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
                                                    const T *__restrict__ D, T *__restrict__ y,
-                                                   T *__restrict__ x, int k) {
+                                                   T *__restrict__ x, int k, const int *__restrict__ cols = nullptr) {
   BA_VT
   __shared__ T zk[NB], xk[NB], part[2][NB];
   const int tid = threadIdx.x;
@@ -1189,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_bwd_step(const T *__restrict__ S, const
     if (tid < NB) x[(int64_t)k * NB + tid] = xk[tid];
     return;
   }
-  const int j = blockIdx.x - 1;  // 0 .. k-1
+  const int j = cols ? cols[blockIdx.x - 1] : blockIdx.x - 1;  // 0 .. k-1 (block-sparse S: the tile columns of row k's pattern)
   const T *Lkj = S + tix(co, k, j) * NB * NB;
   T s = 0;
   for (int r = half * 64; r < half * 64 + 64; r++) s += Lkj[r * NB + c] * xk[r];
@@ -1366,6 +1370,8 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->own_pref) (void)hipFree(w->own_pref);
   if (w->flag_sum) (void)hipFree(w->flag_sum);
   if (w->ready) (void)hipFree(w->ready);
+  if (w->prow) (void)hipFree(w->prow);
+  if (w->lcol) (void)hipFree(w->lcol);
   if (w->hoist) (void)hipStreamDestroy(w->hoist);
   if (w->ev_top) (void)hipEventDestroy(w->ev_top);
   if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
@@ -1475,7 +1481,11 @@ static int launch_pairtrsm(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *V1, 
 // priority stream, bulk on a CU-masked stream -- measured 40-51 ms; masking only 1 / 2 / 4 of the 256 CUs off the bulk
 // stream for a hoisted diagonal kernel 42 / 46 / 59 ms: CU-masked streams are slow here, and that code is gone.)
 template <typename T>
+int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b);
+
+template <typename T>
 int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b) {
+  if (w->sparse && !p->comm.active()) return dense_ldl_factor_sparse(p, w, st, zero_pivot, d_b);
   const int nt = (int)w->nt;
   const int64_t panel = (int64_t)nt * NB * NB;
   T *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
@@ -1534,6 +1544,139 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
       BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_chain, 0));  // join: the hoisted workgroup's outputs are written
     else
       launch_diag(p, w, k + 2, st);
+  }
+  BA_HIP_CHECK(hipGetLastError());
+  if (zero_pivot) {
+    int h = 0;
+    BA_HIP_CHECK(hipMemcpyAsync(&h, w->flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    BA_HIP_CHECK(hipStreamSynchronize(st));
+    *zero_pivot = h;
+  }
+  return BA_OK;
+}
+
+// ---- block-sparse reduced camera system ---------------------------------------------------------------------------------
+// Real bundle-adjustment problems do not connect every camera pair: S has empty 9 x 9 blocks, and the reference's sparse
+// LDL' exploits that (symbolic phase src/ldl_aux.jl:82-119, numeric src/ldl_aux.jl:122-201).  Here the sparsity is kept at
+// the granularity the matrix cores work in: a tile is in the pattern when some camera pair of the Schur key list lands in
+// it, and the symbolic factorisation is done per tile column PAIR (the unit of the schedule): the rows U_q of pair q are
+// the tile rows below it with a pattern tile in either column, and every tile (i, j), i >= j, i, j in U_q, joins the
+// pattern (fill).  Taking the union of the two columns' rows keeps ONE row list per pair; a tile whose operands are
+// structurally zero receives a zero update (correct, a little wasted work when the two columns differ).
+// The numeric phase is the in-order pair schedule with row lists: diag(k), panel solve of column k over {k+1} + U_q,
+// column update, diag(k+1), panel solve of column k+1 over U_q, pair update over the lower tiles of U_q x U_q.  Tiles
+// outside the pattern are never read or written: they hold the zeros of the assembly's memset.
+void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ /* nt x nt, lower, row-major; gets the fill */, TilePattern *out) {
+  const int npairs = (int)((nt + 1) / 2);
+  out->nt = nt;
+  out->prow_ptr.assign(1, 0);
+  out->prow.clear();
+  double tiles_sparse = 0, tiles_dense = 0;
+  std::vector<int> U;
+  for (int q = 0; q < npairs; q++) {
+    const int k = 2 * q;
+    U.clear();
+    for (int64_t i = k + 2; i < nt; i++)
+      if (occ[(size_t)(i * nt + k)] || (k + 1 < nt && occ[(size_t)(i * nt + k + 1)])) U.push_back((int)i);
+    for (size_t a = 0; a < U.size(); a++)
+      for (size_t b = 0; b <= a; b++) occ[(size_t)((int64_t)U[a] * nt + U[b])] = 1;
+    if (k + 1 < nt) {
+      occ[(size_t)((int64_t)(k + 1) * nt + k)] = 1;
+      out->prow.push_back(k + 1);  // the list of pair q starts with tile row k+1 (the panel solve of column k needs it)
+      for (int i : U) {
+        occ[(size_t)((int64_t)i * nt + k)] = 1;  // union of the two columns' rows
+        occ[(size_t)((int64_t)i * nt + k + 1)] = 1;
+      }
+    }
+    for (int i : U) out->prow.push_back(i);
+    out->prow_ptr.push_back((int)out->prow.size());
+    const double m = (double)(nt - k - 2 > 0 ? nt - k - 2 : 0), u = (double)U.size();
+    tiles_sparse += u * (u + 1) / 2;
+    tiles_dense += m * (m + 1) / 2;
+  }
+  out->lcol_ptr.assign(1, 0);
+  out->lcol.clear();
+  int64_t ntiles = 0;
+  for (int64_t i = 0; i < nt; i++) {
+    for (int64_t j = 0; j < i; j++)
+      if (occ[(size_t)(i * nt + j)]) {
+        out->lcol.push_back((int)j);
+        ntiles++;
+      }
+    out->lcol_ptr.push_back((int)out->lcol.size());
+  }
+  out->tile_fill = (double)(ntiles + nt) / ((double)nt * (double)(nt + 1) / 2);
+  out->flop_fill = tiles_dense > 0 ? tiles_sparse / tiles_dense : 1.0;
+}
+
+template <typename T>
+int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {
+  if (w->prow) (void)hipFree(w->prow);
+  if (w->lcol) (void)hipFree(w->lcol);
+  w->prow = w->lcol = nullptr;
+  w->pat = pat;
+  w->sparse = pat != nullptr;
+  if (!pat) return BA_OK;
+  BA_HIP_CHECK(hipMalloc((void **)&w->prow, (pat->prow.size() + 1) * sizeof(int)));
+  BA_HIP_CHECK(hipMalloc((void **)&w->lcol, (pat->lcol.size() + 1) * sizeof(int)));
+  if (!pat->prow.empty()) BA_HIP_CHECK(hipMemcpy(w->prow, pat->prow.data(), pat->prow.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!pat->lcol.empty()) BA_HIP_CHECK(hipMemcpy(w->lcol, pat->lcol.data(), pat->lcol.size() * sizeof(int), hipMemcpyHostToDevice));
+  return BA_OK;
+}
+
+// the in-order pair schedule over the pattern (see above); d_b != null: the forward substitution rides along
+template <typename T>
+int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b) {
+  const int nt = (int)w->nt;
+  const TilePattern *pat = w->pat;
+  T *V0 = w->V, *V1 = w->V + (int64_t)nt * NB * NB;
+  T *y = w->D + w->nt * NB;
+  BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
+  w->hoisting = false;
+  for (int k = 0, q = 0; k < nt; k += 2, q++) {
+    const int l0 = pat->prow_ptr[(size_t)q], l1 = pat->prow_ptr[(size_t)q + 1];
+    const int c1 = l1 - l0;                      // {k+1} + U_q
+    const int c2 = c1 > 0 ? c1 - 1 : 0;          // U_q
+    const int *rows1 = w->prow + l0, *rows2 = w->prow + l0 + 1;
+    launch_diag(p, w, k, st);
+    if (c1 == 0) {  // last, single tile column: y_k only
+      if (d_b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k, (const int *)nullptr);
+      break;
+    }
+    {
+      ProfScope ps(p, PC_LDL_TRSM, st);
+      if (d_b)
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, true>), dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+                           w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, V0, k, d_b, y, rows1);
+      else
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+                           w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, V0, k, d_b, y, rows1);
+    }
+    {
+      ProfScope ps(p, PC_LDL_SYRK, st);
+      hipLaunchKernelGGL(k_ldl_col_rs<T>, dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, V0, k, rows1);
+    }
+    launch_diag(p, w, k + 1, st);
+    if (c2 == 0) {
+      if (d_b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k + 1, (const int *)nullptr);
+      continue;
+    }
+    {
+      ProfScope ps(p, PC_LDL_TRSM, st);
+      if (d_b)
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, true>), dim3(4 * c2), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+                           w->Linv + (int64_t)(k + 1) * NB * NB, w->D + (int64_t)(k + 1) * NB, V1, k + 1, d_b, y, rows2);
+      else
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * c2), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+                           w->Linv + (int64_t)(k + 1) * NB * NB, w->D + (int64_t)(k + 1) * NB, V1, k + 1, d_b, y, rows2);
+    }
+    {
+      ProfScope ps(p, PC_LDL_UPDATE, st);
+      const int nblk = c2 * (c2 + 1) / 2;
+      hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S,
+                         w->col_off, V0, V1, k, k + 2, nt, nblk, (int *)nullptr, (const int *)nullptr, (const int64_t *)nullptr, 0, 0,
+                         1, rows2);
+    }
   }
   BA_HIP_CHECK(hipGetLastError());
   if (zero_pivot) {
@@ -1687,6 +1830,19 @@ int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool
   if (!forward_done)
     for (int k = 0; k < nt; k++)
       hipLaunchKernelGGL(k_fwd_step<T>, dim3(nt - k), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k);
+  if (w->sparse && !p->comm.active()) {  // block-sparse S: one tile row per launch over the tile columns of its pattern
+    const TilePattern *pat = w->pat;
+    if (!forward_done) {
+      ba_set_error("block-sparse reduced camera system: the forward substitution rides along with the factorisation");
+      return BA_ERR_ARG;
+    }
+    for (int k = nt - 1; k >= 0; k--) {
+      const int c0 = pat->lcol_ptr[(size_t)k], c1 = pat->lcol_ptr[(size_t)k + 1];
+      hipLaunchKernelGGL(k_bwd_step<T>, dim3(1 + (c1 - c0)), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, k, w->lcol + c0);
+    }
+    BA_HIP_CHECK(hipGetLastError());
+    return BA_OK;
+  }
   static const bool pair_off = [] { const char *e = getenv("BA_BWD_PAIR"); return e && e[0] == '0'; }();
   int k = nt - 1;
   if (!pair_off)
@@ -1781,6 +1937,8 @@ template void dense_ldl_free<double>(DenseLDLT<double> *);
 template void dense_ldl_free<float>(DenseLDLT<float> *);
 template int dense_ldl_factor<double>(ba_problem *, DenseLDLT<double> *, hipStream_t, int *, double *);
 template int dense_ldl_factor<float>(ba_problem *, DenseLDLT<float> *, hipStream_t, int *, float *);
+template int dense_ldl_use_pattern<double>(DenseLDLT<double> *, const TilePattern *);
+template int dense_ldl_use_pattern<float>(DenseLDLT<float> *, const TilePattern *);
 template int dense_ldl_factor_dist<double>(ba_problem *, DenseLDLT<double> *, hipStream_t);
 template int dense_ldl_factor_dist<float>(ba_problem *, DenseLDLT<float> *, hipStream_t);
 template int dense_ldl_solve<double>(ba_problem *, DenseLDLT<double> *, double *, hipStream_t, bool);

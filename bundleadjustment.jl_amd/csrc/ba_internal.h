@@ -64,6 +64,15 @@ struct ProfSlot {
   int64_t calls = 0;
 };
 
+// tile pattern of a block-sparse reduced camera system after the symbolic factorisation (ba_dense_ldl.hip)
+struct TilePattern {
+  int64_t nt = 0;
+  std::vector<int> prow_ptr, prow;  // pair q: [k+1] + the tile rows of its pattern (k = 2q), ascending
+  std::vector<int> lcol_ptr, lcol;  // tile row i: the tile columns j < i of its pattern, ascending
+  double tile_fill = 1.0;           // pattern tiles (with fill) / all lower tiles
+  double flop_fill = 1.0;           // trailing-update tiles of the pattern / of the dense factorisation
+};
+
 template <typename T>
 struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*ncams padded to nt*NB
   int64_t n = 0, nt = 0;
@@ -90,6 +99,10 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   hipEvent_t ev_chain = nullptr;  // recorded behind each hoisted diagonal kernel
   // distributed factorisation with look-ahead: panels of pair q received (transfer stream), update of pair q launched
   hipEvent_t ev_recv[2] = {nullptr, nullptr}, ev_upd[2] = {nullptr, nullptr};
+  // block-sparse S (one GPU): the pattern's row / column lists on the device; null pattern = dense
+  bool sparse = false;
+  const TilePattern *pat = nullptr;
+  int *prow = nullptr, *lcol = nullptr;
   hipEvent_t ev_dtop = nullptr, ev_dchain = nullptr;  // distributed factorisation: fork behind the reduce of S, end of the owner's panel chain
 };
 typedef DenseLDLT<double> DenseLDL;
@@ -187,6 +200,11 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
 // No fused forward substitution: call dense_ldl_solve(..., forward_done = false).
 template <typename T>
 int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st);
+// block-sparse S: symbolic factorisation of the tile occupancy `occ` (nt x nt, lower, row-major; receives the fill) per
+// tile column pair, and its use by a workspace (null: dense).  The pattern object must outlive the workspace.
+void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ, TilePattern *out);
+template <typename T>
+int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat);
 // solve S x = b for one right-hand side held in d_b (length nt*NB, overwritten by x)
 template <typename T>
 int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool forward_done);

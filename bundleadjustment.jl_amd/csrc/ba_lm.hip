@@ -111,6 +111,16 @@ int build_tasks(ba_problem *p, SchurTasks *T) {
   }
   T->nkeys = (int64_t)key_ca.size();
   T->ntasks = ntasks;
+  {  // which 128 x 128 tiles of S receive a 9 x 9 block (a block straddles at most two tile rows and two tile columns)
+    const int64_t nt = std::max<int64_t>(1, (9 * ncams + NB - 1) / NB);
+    T->tile_occ.assign((size_t)(nt * nt), 0);
+    for (size_t q = 0; q < key_ca.size(); q++) {
+      const int64_t r0 = 9 * (int64_t)key_ca[q], c0 = 9 * (int64_t)key_cb[q];
+      for (int64_t ti = r0 / NB; ti <= (r0 + 8) / NB; ti++)
+        for (int64_t tj = c0 / NB; tj <= (c0 + 8) / NB; tj++)
+          if (ti >= tj) T->tile_occ[(size_t)(ti * nt + tj)] = 1;
+    }
+  }
   {  // chunking of the long keys (see SchurTasks)
     // chunk size: the partial blocks cost traffic, so as large as leaves ~8 k chunks for the chip (sweeps on MI355X: LadyBug-49
     // 4 / 8 / 16 / 32 -> 0.107 / 0.070 / 0.058 / 0.065 ms; Dubrovnik-356 8 / 32 / 128 / 256 -> 1.12 / 0.68 / 0.58 / 0.57 ms
@@ -173,6 +183,8 @@ struct LMState {
 
 struct LMWorkFull : LMWork {
   LMState s;
+  TilePattern pattern;       // tile pattern of S after the symbolic factorisation (ensure_dense)
+  bool use_pattern = false;  // the block-sparse list schedule is in use on this handle
   // facto_type = Float32 (src/lm.jl:170-173): Float32 copy of the reduced camera system, allocated on first use
   DenseLDLT<float> ldl32;
   float *rhs32 = nullptr;
@@ -235,6 +247,7 @@ static int ensure_xf32(ba_problem *p, LMWorkFull *w) {
 static int ensure_f32(LMWorkFull *w) {
   if (w->have32) return BA_OK;
   BA_CHECK(dense_ldl_alloc<float>(&w->ldl32, w->n, nullptr, w->ldl.world, w->ldl.rank));
+  if (w->use_pattern) BA_CHECK(dense_ldl_use_pattern(&w->ldl32, &w->pattern));
   BA_HIP_CHECK(hipMalloc((void **)&w->rhs32, (size_t)w->npad * sizeof(float)));
   w->have32 = true;
   return BA_OK;
@@ -302,7 +315,18 @@ static int ensure_dense(ba_problem *p, LMWorkFull *w) {
   if (w->ldl.S) return BA_OK;
   BA_CHECK(dense_ldl_alloc_S(&w->ldl));
   BA_CHECK(dmalloc(&w->Yobs, 6 * p->nobs));
-  return build_tasks(p, &w->tasks);
+  BA_CHECK(build_tasks(p, &w->tasks));
+  // Block-sparse reduced camera system (one GPU): symbolic factorisation of the tile occupancy; the list schedule is used
+  // when the pattern's trailing updates are at most 60 % of the dense factorisation's (BA_SPARSE_S=1 / 0 forces it on /
+  // off).  Every camera pair sharing points (the default synthetic generator, small problems) gives flop_fill = 1: dense.
+  tile_pattern_build(w->ldl.nt, w->tasks.tile_occ, &w->pattern);
+  w->tasks.tile_occ.clear();
+  w->tasks.tile_occ.shrink_to_fit();
+  const char *e = getenv("BA_SPARSE_S");
+  const bool want = e ? e[0] != '0' : (w->pattern.flop_fill <= 0.6 && w->ldl.nt >= 8);
+  w->use_pattern = want && !p->comm.active();
+  if (w->use_pattern) BA_CHECK(dense_ldl_use_pattern(&w->ldl, &w->pattern));
+  return BA_OK;
 }
 
 void lm_free(ba_problem *p) {
@@ -609,7 +633,8 @@ static bool graphs_allowed(ba_problem *p, LMWorkFull *w) {
   if (w->g_off || p->prof_on || p->comm.active() || w->f16 || w->pcg) return false;  // per-kernel events / communicator / Float16 path
   // the hoisted-diagonal schedule of large factorisations has a kernel wait for a flag raised by a kernel running
   // beside it: only with real streams is that concurrency certain (and the graphs gain nothing at that size)
-  if (w->ldl.nt >= 34) return false;  // = HOIST_MIN_TILES + 2 of dense_ldl_factor (above its HOIST_MAX_TILES graphs gain nothing either)
+  // (the block-sparse list schedule never hoists and is bound by its chain of short launches: recorded at any size)
+  if (w->ldl.nt >= 34 && !w->use_pattern) return false;  // = HOIST_MIN_TILES + 2 of dense_ldl_factor (above its HOIST_MAX_TILES graphs gain nothing either)
   const char *e = getenv("BA_LM_GRAPH");
   return !(e && e[0] == '0');
 }
@@ -752,6 +777,22 @@ static int lm_step_impl(ba_problem *p, const double *x, double lambda, double *d
   if (half_sq_model) *half_sq_model = 0.5 * w->s.h_sh[SH_MODEL];
   if (cg_iters) *cg_iters = (int)w->n_cg;
   w->pcg = false;
+  return BA_OK;
+}
+
+extern "C" int ba_lm_schur_pattern(ba_problem *p, double *tile_fill, double *flop_fill, int *sparse_schedule) {
+  if (!p || !p->lm) {
+    ba_set_error("ba_lm_schur_pattern: no direct solve has run on this handle yet");
+    return BA_ERR_ARG;
+  }
+  LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
+  if (!w->ldl.S) {
+    ba_set_error("ba_lm_schur_pattern: no direct solve has run on this handle yet");
+    return BA_ERR_ARG;
+  }
+  if (tile_fill) *tile_fill = w->pattern.tile_fill;
+  if (flop_fill) *flop_fill = w->pattern.flop_fill;
+  if (sparse_schedule) *sparse_schedule = w->use_pattern ? 1 : 0;
   return BA_OK;
 }
 

@@ -20,6 +20,7 @@ struct SchurTasks {
   int *skey = nullptr, *skey_c0 = nullptr;                        // split keys: key id, first chunk (nsplit + 1 entries)
   int *chunk_t0 = nullptr, *chunk_t1 = nullptr;                   // chunks: task range
   double *partial = nullptr;                                      // nchunks x 81
+  std::vector<unsigned char> tile_occ;                            // host: nt x nt lower tile occupancy of S by the keys (before fill)
 };
 
 // scalar slots of LMWork::scal (device) / h_scal (pinned host)

@@ -131,3 +131,12 @@ def lm_step(nlp, x, lam, want_jtr=True, facto_type=None, pcg=None):
     fn = _lib.lib().ba_lm_step_f32 if f32 else _lib.lib().ba_lm_step
     _lib.check(fn(nlp.handle, _lib.ptr(x), float(lam), _lib.ptr(delta), C.byref(half), _lib.ptr(jtr) if want_jtr else None))
     return delta, half.value, jtr
+
+
+def schur_pattern(nlp):
+    """(tile_fill, flop_fill, sparse_schedule) of the reduced camera system of a handle that has run a direct solve
+    (ba_lm_schur_pattern): the fraction of the lower 128 x 128 tiles in the factor's pattern, the fraction of the dense
+    factorisation's trailing-update tiles that pattern needs, and whether the block-sparse list schedule is in use."""
+    tf, ff, sp = C.c_double(0), C.c_double(0), C.c_int(0)
+    _lib.check(_lib.lib().ba_lm_schur_pattern(nlp.handle, C.byref(tf), C.byref(ff), C.byref(sp)))
+    return tf.value, ff.value, bool(sp.value)

@@ -5,7 +5,7 @@ Generator spec: unit-ball points; rotation vectors axis*a
 the origin down -z so that P1.z is in (-8, -4) (never 0, :26-31); f ~ U(400, 1800); k1 ~ -U(0,5)e-7; k2 ~ U(0,1)e-12
 (magnitudes of the fixture of test/runtests.jl:18); per-point degree >= 2 from a shifted geometric law adjusted so
 that the degrees sum to nobs exactly; cameras of a point distinct and uniformly drawn (=> the reduced camera matrix
-is dense); observations sorted by point then camera (BAL order, test/runtests.jl:16-17);
+is dense; `locality` draws them from a window of consecutive cameras instead: block-banded S, see make_problem); observations sorted by point then camera (BAL order, test/runtests.jl:16-17);
 pt2d = projection(x_true) + N(0, 0.5^2) px; x0 = x_true with points + N(0, 0.02^2), cameras * (1 + N(0, 1e-3^2)).
 """
 import bz2
@@ -60,8 +60,15 @@ def _degrees(rng, npnts, nobs, ncams):
     return deg
 
 
-def make_problem(ncams, npnts, nobs, seed=BASE_SEED):
-    """-> dict(cam_idx1, pnt_idx1, pt2d, x0, x_true, ncams, npnts, nobs) in the reference's conventions."""
+def make_problem(ncams, npnts, nobs, seed=BASE_SEED, locality=None):
+    """-> dict(cam_idx1, pnt_idx1, pt2d, x0, x_true, ncams, npnts, nobs) in the reference's conventions.
+
+    locality (None or a fraction in (0, 1]): None draws the cameras of a point uniformly from ALL cameras -- every camera
+    pair then shares points and the reduced camera matrix S is dense (its block fill is 1).  With locality = w a point is
+    seen only by cameras of one window of round(w * ncams) consecutive cameras (window start uniform): cameras further
+    apart than the window share no point, S is block-banded with half bandwidth w * ncams and its 9 x 9 block fill is
+    about 2w - w^2 (schur_fill() measures it).  Real BAL problems lie in between (sequential captures: narrow band plus loop
+    closures); the default stays dense -- the worst case for the factorisation."""
     rng = np.random.default_rng(seed)
     # points in the unit ball
     g = rng.standard_normal((npnts, 3))
@@ -80,16 +87,24 @@ def make_problem(ncams, npnts, nobs, seed=BASE_SEED):
     k2 = rng.uniform(0.0, 1.0, size=ncams) * 1e-12
     cams = np.column_stack([rvec, tvec, k1, k2, f])
     # observation graph
-    deg = _degrees(rng, npnts, nobs, ncams)
-    pnt0 = np.repeat(np.arange(npnts, dtype=np.int64), deg)
-    cam0 = rng.integers(0, ncams, size=nobs, dtype=np.int64)
-    for _ in range(200):
+    if locality is None:
+        deg = _degrees(rng, npnts, nobs, ncams)
+        pnt0 = np.repeat(np.arange(npnts, dtype=np.int64), deg)
+        lo_cam = np.zeros(nobs, dtype=np.int64)
+        width = ncams
+    else:
+        width = int(min(ncams, max(2, round(float(locality) * ncams))))
+        deg = _degrees(rng, npnts, nobs, width)
+        pnt0 = np.repeat(np.arange(npnts, dtype=np.int64), deg)
+        lo_cam = np.repeat(rng.integers(0, ncams - width + 1, size=npnts, dtype=np.int64), deg)  # window start of the point
+    cam0 = lo_cam + rng.integers(0, width, size=nobs, dtype=np.int64)
+    for _ in range(400):
         order = np.lexsort((cam0, pnt0))
-        cam0 = cam0[order]
+        cam0, lo_cam = cam0[order], lo_cam[order]
         dup = np.flatnonzero((pnt0[1:] == pnt0[:-1]) & (cam0[1:] == cam0[:-1])) + 1
         if dup.size == 0:
             break
-        cam0[dup] = rng.integers(0, ncams, size=dup.size, dtype=np.int64)
+        cam0[dup] = lo_cam[dup] + rng.integers(0, width, size=dup.size, dtype=np.int64)
     else:
         raise RuntimeError("could not draw distinct cameras per point")
     proj = project(pts[pnt0], cams[cam0])
@@ -102,7 +117,40 @@ def make_problem(ncams, npnts, nobs, seed=BASE_SEED):
                 ncams=int(ncams), npnts=int(npnts), nobs=int(nobs))
 
 
-def make_named(name, seed_offset=0, scale=1.0):
+def schur_fill(prob, tile=128):
+    """(block fill, tile fill) of the reduced camera matrix of a problem: the fraction of camera pairs (a >= b) that share at
+    least one point, and the fraction of the lower tile x tile tiles of S (rows / columns 9 * camera) that hold such a pair
+    -- before factorisation (the factor fills in inside the profile)."""
+    ncams = prob["ncams"]
+    cam0 = np.asarray(prob["cam_idx1"]) - 1
+    pnt0 = np.asarray(prob["pnt_idx1"]) - 1
+    order = np.lexsort((cam0, pnt0))
+    cam0, pnt0 = cam0[order], pnt0[order]
+    start = np.flatnonzero(np.r_[True, pnt0[1:] != pnt0[:-1]])
+    deg = np.diff(np.r_[start, len(pnt0)])
+    pairs = set()
+    share = np.zeros((ncams, ncams), dtype=bool) if ncams <= 20000 else None
+    if share is None:
+        raise ValueError("schur_fill: too many cameras for the dense indicator")
+    for d in np.unique(deg):  # all points of one degree at once
+        idx = start[deg == d]
+        cams = cam0[idx[:, None] + np.arange(d)[None, :]]  # (npoints_d, d), ascending per row
+        for a in range(d):
+            for b in range(a + 1):
+                share[cams[:, a], cams[:, b]] = True
+    nblk = ncams * (ncams + 1) // 2
+    block_fill = float(np.count_nonzero(np.tril(share))) / nblk
+    nt = (9 * ncams + tile - 1) // tile
+    occ = np.zeros((nt, nt), dtype=bool)
+    ia, ib = np.nonzero(np.tril(share))
+    for da in (0, 8):
+        for db in (0, 8):
+            occ[(9 * ia + da) // tile, (9 * ib + db) // tile] = True
+    tile_fill = float(np.count_nonzero(np.tril(occ))) / (nt * (nt + 1) // 2)
+    return block_fill, tile_fill
+
+
+def make_named(name, seed_offset=0, scale=1.0, locality=None):
     """One of SHAPES, optionally shrunk by `scale` (observations per point kept)."""
     ncams, npnts, nobs = SHAPES[name]
     if scale != 1.0:
@@ -111,7 +159,7 @@ def make_named(name, seed_offset=0, scale=1.0):
         nobs = max(2 * npnts2, int(round(nobs * npnts2 / npnts)))
         nobs = min(nobs, ncams * npnts2)
         npnts = npnts2
-    return make_problem(ncams, npnts, nobs, BASE_SEED + seed_offset)
+    return make_problem(ncams, npnts, nobs, BASE_SEED + seed_offset, locality=locality)
 
 
 def as_arrays(prob, T=np.float64):

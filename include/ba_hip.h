@@ -218,6 +218,15 @@ int ba_lm_step_f32(ba_problem *p, const double *x, double lambda, double *delta,
 int ba_lm_step_pcg(ba_problem *p, const double *x, double lambda, double tol, int max_iter, double *delta,
                    double *half_sq_model, double *jtr, int *cg_iters_out);
 
+/* Block-sparse reduced camera system.  Cameras that share no point leave empty 9 x 9 blocks in S; the reference's sparse
+ * LDL^T exploits that (symbolic phase src/ldl_aux.jl:82-119, numeric :122-201).  The device keeps the sparsity at the
+ * granularity of its 128 x 128 tiles: on the first direct solve the tile occupancy of the Schur key list goes through a
+ * symbolic factorisation per tile column pair, and when the pattern's trailing updates are at most 60 % of the dense
+ * factorisation's, assembly-side zeros are skipped by a list-driven schedule (one GPU; BA_SPARSE_S=1 / 0 forces it on /
+ * off).  tile_fill: pattern tiles (with fill) / all lower tiles; flop_fill: trailing-update tiles of the pattern / of the
+ * dense factorisation; sparse_schedule: 1 when the list schedule is in use.  Valid after the first direct solve. */
+int ba_lm_schur_pattern(ba_problem *p, double *tile_fill, double *flop_fill, int *sparse_schedule);
+
 /* ---- per-kernel timing (hipEvent pairs on the handle's stream) ------------------------------------ */
 int ba_profile_enable(ba_problem *p, int on);
 int ba_profile_reset(ba_problem *p);
