@@ -314,7 +314,7 @@ static int lm_ensure(ba_problem *p) {
 static int ensure_dense(ba_problem *p, LMWorkFull *w) {
   if (w->ldl.S) return BA_OK;
   BA_CHECK(dense_ldl_alloc_S(&w->ldl));
-  BA_CHECK(dmalloc(&w->Yobs, 24 * p->nobs));  // packed records [B_b | Y_b] of the Schur tasks (k_obs_y)
+  BA_CHECK(dmalloc(&w->Yobs, 6 * p->nobs));
   BA_CHECK(build_tasks(p, &w->tasks));
   // Block-sparse reduced camera system (one GPU): symbolic factorisation of the tile occupancy; the list schedule is used
   // when the pattern's trailing updates are at most 60 % of the dense factorisation's (BA_SPARSE_S=1 / 0 forces it on /

@@ -31,7 +31,7 @@ struct LMWork {
   double *x = nullptr, *x_trial = nullptr, *delta = nullptr;
   double *r = nullptr, *r_trial = nullptr, *J = nullptr;
   double *Hpp = nullptr, *gp = nullptr, *Uinv = nullptr, *u = nullptr;
-  double *Yobs = nullptr;                // 24/obs: packed task records [B_b (18) | Y_b = U^-1 A_b' (6)] of the current damping
+  double *Yobs = nullptr;                // 6/obs: U^-1 A_b' of the current damping
   bool model_done = false;               // the step's model value was formed by the back-substitution pass
   double *Hcc = nullptr, *gc = nullptr;  // gc: 9*ncams
   double *hdiag = nullptr;               // npad: diag of the camera block of J'J summed over all ranks (column scalings)

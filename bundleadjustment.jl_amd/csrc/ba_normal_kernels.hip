@@ -354,38 +354,31 @@ __device__ inline void s_store(double *S, const int64_t *__restrict__ co, int64_
   S[(tix(co, ti, tj) * NB + (gr - ti * NB)) * NB + (gc - tj * NB)] = v;
 }
 
-// Packed record of observation b for the Schur tasks, 24 doubles = 192 bytes, 64-byte aligned:
-//     P_b = [ B_b (2 x 9: the camera part of its Jacobian block, rows 0 and 1) | Y_b = U_p^-1 A_b' (3 x 2, row-major) ]
-// Y is the point-side half of Q_ab = A_a Y_b and changes with the damping; B is copied beside it so that a task (a, b) is
-// TWO contiguous aligned reads -- the row J_a and the record P_b, 384 bytes, exactly the algorithmic bytes -- instead of
-// one row plus two unaligned 72-byte segments of J_b plus 48 bytes of Y_b from a third array (PMC: 660 bytes per task,
-// profiles/r02_f_pmc_traffic.json).  One lane per observation; the extra 144 bytes written per observation and trial step
-// are 0.7 GB on Venice against 4 GB saved in the task gathers.
-constexpr int PREC = 24;  // doubles per packed record
+// Y_b = U_p^-1 A_b'  (3x2, row-major) per observation: the point-side half of Q_ab = A_a Y_b
 __global__ __launch_bounds__(BLK) void k_obs_y(int64_t nobs, const int *__restrict__ pnt0, const double *__restrict__ J,
                                                 const double *__restrict__ Uinv, double *__restrict__ Y) {
   int64_t o = (int64_t)blockIdx.x * BLK + threadIdx.x;
   if (o >= nobs) return;
   const double *Jo = J + 24 * o, *U = Uinv + 6 * (int64_t)pnt0[o];
   const double a00 = Jo[0], a01 = Jo[1], a02 = Jo[2], a10 = Jo[12], a11 = Jo[13], a12 = Jo[14];
-  double *y = Y + PREC * o;
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-    y[i] = Jo[3 + i];
-    y[9 + i] = Jo[15 + i];
-  }
-  y[18] = U[0] * a00 + U[1] * a01 + U[2] * a02;
-  y[19] = U[0] * a10 + U[1] * a11 + U[2] * a12;
-  y[20] = U[1] * a00 + U[3] * a01 + U[4] * a02;
-  y[21] = U[1] * a10 + U[3] * a11 + U[4] * a12;
-  y[22] = U[2] * a00 + U[4] * a01 + U[5] * a02;
-  y[23] = U[2] * a10 + U[4] * a11 + U[5] * a12;
+  double *y = Y + 6 * o;
+  y[0] = U[0] * a00 + U[1] * a01 + U[2] * a02;
+  y[1] = U[0] * a10 + U[1] * a11 + U[2] * a12;
+  y[2] = U[1] * a00 + U[3] * a01 + U[4] * a02;
+  y[3] = U[1] * a10 + U[3] * a11 + U[4] * a12;
+  y[4] = U[2] * a00 + U[4] * a01 + U[5] * a02;
+  y[5] = U[2] * a10 + U[4] * a11 + U[5] * a12;
 }
 
+// (Round 3, measured and NOT adopted: a packed per-observation record [B_b (18) | Y_b (6)], 192 aligned bytes, so that a
+// task is two contiguous reads -- exactly its 384 algorithmic bytes instead of the ~660 the PMC counters show.  rocprofv3 on
+// Venice: k_schur_blocks 2.66 -> 2.58 ms, but k_obs_y, which then writes 192 instead of 48 bytes per observation, 0.28 ->
+// 0.45 ms and k_schur_chunks 0.36 -> 0.41 ms: a net loss.  The kernel is not bound by the bytes of its gathers: at 80 VGPRs
+// six waves per SIMD keep 12 task pairs in flight, and the request latency of that many dependent gathers is what one sees.)
 // One wave per key.  The sum over the key's tasks of B_a' (Q_ab B_b) is a (9 x 2t)(2t x 9) product: two tasks fill
 // the four k-slots of one v_mfma_f64_16x16x4_f64 (slot = (task, image row alpha)); the A operand is B_a[alpha][i], the
 // B operand G[alpha][j] = Q_ab[alpha][:] B_b[:][j] with Q_ab = A_a Y_b.  Per task one coalesced load of
-// J_a (24) and the packed record P_b (B_b 18 + Y_b 6, k_obs_y) is staged in the wave's LDS slot.
+// J_a (24), the camera rows of J_b (18) and Y_b (6) is staged in the wave's LDS slot.
 typedef double d4s __attribute__((ext_vector_type(4)));
 #ifndef BA_SCHUR_PF
 #define BA_SCHUR_PF 2  // task pairs in flight per wave: 2, 3, 4 measure the same (6.29-6.42 ms on the sweep box), 6 and 8 slower (7.7)
@@ -396,9 +389,9 @@ __device__ inline d4s schur_accumulate(int t_begin, int t_end, const int *__rest
                                        const double *__restrict__ J, const double *__restrict__ Y, double (*stage)[48]) {
   const int lane = threadIdx.x & 63;
   const int fr = lane & 15, fk = lane >> 4, tl = fk >> 1, al = fk & 1;
-  // element `lane` (< 48) of a task record: J_a[0..23] | P_b[0..23] = B_b (2 x 9) | Y_b[0..5]   (see k_obs_y)
+  // element `lane` (< 48) of a task record: J_a[0..23] | J_b camera rows (2 x 9) | Y_b[0..5]
   const int e = lane;
-  const int eoff = e < 24 ? e : e - 24;
+  const int eoff = e < 24 ? e : (e < 33 ? e - 24 + 3 : (e < 42 ? e - 33 + 15 : e - 42));
   d4s acc = {0, 0, 0, 0};
   // Latency hiding inside one wave: task indices come 64 at a time with one coalesced load and are handed out with
   // v_readlane; the records of the next task pairs are in flight (registers) while the current pair is multiplied.
@@ -413,7 +406,8 @@ __device__ inline d4s schur_accumulate(int t_begin, int t_end, const int *__rest
       if (tq >= nin) return 0.0;
       const int oa = __builtin_amdgcn_readlane(my_oa, tq), ob = __builtin_amdgcn_readlane(my_ob, tq);
       if (e < 24) return J[24 * (int64_t)oa + eoff];
-      if (e < 48) return Y[PREC * (int64_t)ob + eoff];
+      if (e < 42) return J[24 * (int64_t)ob + eoff];
+      if (e < 48) return Y[6 * (int64_t)ob + eoff];
       return 0.0;
     };
     double pf[SCHUR_PF][2];
