@@ -13,11 +13,11 @@ except ImportError:  # pragma: no cover
     _torch = None
 from . import _lib
 from ._lib import BAError, SQDException, device_count
-from .lm import GenericExecutionStats, Levenberg_Marquardt, lm_step, schur_pattern
+from .lm import GenericExecutionStats, Levenberg_Marquardt, lm_step, schur_pattern, schur_memory
 from .model import BALNLPModel, FeasibilityResidual
 from .readfiles import name, readfile
 from . import synthetic
 from . import parallel
 
 __all__ = ["BALNLPModel", "FeasibilityResidual", "Levenberg_Marquardt", "GenericExecutionStats", "readfile", "name",
-           "BAError", "SQDException", "device_count", "synthetic", "parallel", "lm_step", "schur_pattern"]
+           "BAError", "SQDException", "device_count", "synthetic", "parallel", "lm_step", "schur_pattern", "schur_memory"]

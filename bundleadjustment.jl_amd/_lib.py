@@ -55,7 +55,7 @@ SYMBOLS = [
     "ba_jac_structure_dev", "ba_jac_coord_dev", "ba_jac_coord_f32_dev", "ba_jtr_dev", "ba_dev_malloc", "ba_dev_free",
     "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_memcpy_h2d_on", "ba_memcpy_d2h_on", "ba_synchronize", "ba_lm_solve", "ba_comm_get_unique_id", "ba_lm_set_comm_rccl",
     "ba_lm_set_comm_hook", "ba_comm_stats", "ba_dist_layout",
-    "ba_lm_step", "ba_lm_step_f32", "ba_lm_step_pcg", "ba_lm_schur_pattern", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
+    "ba_lm_step", "ba_lm_step_f32", "ba_lm_step_pcg", "ba_lm_schur_pattern", "ba_lm_schur_memory", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
 ]
 
 _lib = None
@@ -104,6 +104,7 @@ def lib():
     L.ba_lm_step_f32.argtypes = [vp, vp, f64, vp, C.POINTER(f64), vp]
     L.ba_lm_step_pcg.argtypes = [vp, vp, f64, f64, C.c_int, vp, C.POINTER(f64), vp, C.POINTER(C.c_int)]
     L.ba_lm_schur_pattern.argtypes = [vp, C.POINTER(f64), C.POINTER(f64), C.POINTER(C.c_int)]
+    L.ba_lm_schur_memory.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.ba_profile_enable.argtypes = [vp, C.c_int]
     L.ba_profile_reset.argtypes = [vp]
     L.ba_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(f64), C.POINTER(i64), C.POINTER(C.c_int)]

@@ -1014,7 +1014,8 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
                                                         int nblk, int *__restrict__ ready,
                                                         const int *__restrict__ own_cols = nullptr,
                                                         const int64_t *__restrict__ own_pref = nullptr, int m0 = 0,
-                                                        int m_end = 0, int ready_tiles = 1, const int *__restrict__ rows = nullptr) {
+                                                        int m_end = 0, int ready_tiles = 1, const int *__restrict__ rows = nullptr,
+                                                        const T *__restrict__ Lp0 = nullptr, const T *__restrict__ Lp1 = nullptr) {
   BA_VT
   static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -1063,8 +1064,10 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
                           S + tix(co, jo, k + 1) * NB * NB, lds, acc, V1 + (int64_t)(nt + io) * NB * NB,
                           S + tix(co, jo, k + 2) * NB * NB, V1 + (int64_t)(2 * nt + io) * NB * NB, S + tix(co, jo, k + 3) * NB * NB);
   else if (!(DBG & 8))
-    tile_gemm_abt_priv<T, 2>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
-                          S + tix(co, jo, k + 1) * NB * NB, lds, acc);
+    // Lp0 / Lp1 (distributed factorisation with per-rank ownership of S): the L tiles of the two panels come from the panel
+    // buffers the broadcast filled (tile row j at Lp + j NB^2) -- a rank holds only its own tile columns of S
+    tile_gemm_abt_priv<T, 2>(V0 + (int64_t)io * NB * NB, Lp0 ? Lp0 + (int64_t)jo * NB * NB : S + tix(co, jo, k) * NB * NB,
+                          V1 + (int64_t)io * NB * NB, Lp1 ? Lp1 + (int64_t)jo * NB * NB : S + tix(co, jo, k + 1) * NB * NB, lds, acc);
   else
     tile_gemm_abt<T, 2>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
                      S + tix(co, jo, k + 1) * NB * NB, sA, sB, acc);
@@ -1110,12 +1113,13 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
 // A rank that received the panel V = L D of tile column k from its owner rebuilds L_ik = V_i D_k^-1 in its own copy of S
 // (rows i0..nt-1), with the owner's arithmetic (k_ldl_trsm_rs: xv * (1 / d)), so that every rank holds the same bits.
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_scale_panel(T *__restrict__ S, const int64_t *__restrict__ co,
-                                                          const T *__restrict__ V, const T *__restrict__ D_k, int k, int i0) {
+__global__ __launch_bounds__(256) void k_ldl_scale_panel(T *__restrict__ Lcol, const T *__restrict__ V, const T *__restrict__ D_k, int i0) {
+  // Lcol: where the L tiles of this tile column live, tile row i at Lcol + i NB^2 (a column of S is contiguous: S + (co[k] - k)
+  // NB^2; with per-rank ownership of S: a panel buffer)
   BA_VT
   const int i = i0 + blockIdx.x;
   const T *Vi = V + (int64_t)i * NB * NB;
-  T *Sik = S + tix(co, i, k) * NB * NB;
+  T *Sik = Lcol + (int64_t)i * NB * NB;
   const int c2 = threadIdx.x & 63;  // this thread's column pair (2 c2, 2 c2 + 1), the same in every row it touches
   const T inv0 = (T)1 / D_k[2 * c2], inv1 = (T)1 / D_k[2 * c2 + 1];
   for (int r = threadIdx.x >> 6; r < NB; r += 4) {
@@ -1140,7 +1144,8 @@ __device__ inline T wsum(T v) {
 // forward step k: y_k = Linv_k b_k (every workgroup recomputes it; block 0 stores it), then b_i -= L_ik y_k, i > k.
 template <typename T>
 __global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
-                                                   T *__restrict__ b, T *__restrict__ y, int k, const int *__restrict__ rows = nullptr) {
+                                                   T *__restrict__ b, T *__restrict__ y, int k, const int *__restrict__ rows = nullptr,
+                                                   const T *__restrict__ Lcol = nullptr) {
   BA_VT
   __shared__ T yk[NB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1158,7 +1163,7 @@ __global__ __launch_bounds__(256) void k_fwd_step(const T *__restrict__ S, const
     return;
   }
   const int i = rows ? rows[blockIdx.x - 1] : k + blockIdx.x;
-  const T *Lik = S + tix(co, i, k) * NB * NB;
+  const T *Lik = Lcol ? Lcol + (int64_t)i * NB * NB : S + tix(co, i, k) * NB * NB;  // Lcol: panel buffer (per-rank ownership of S)
   const T y0 = yk[2 * lane], y1 = yk[2 * lane + 1];
   for (int rr = 0; rr < 32; rr++) {
     int row = wv * 32 + rr;
@@ -1295,7 +1300,7 @@ void dense_ldl_layout(int64_t nt, int world, std::vector<int64_t> *col_off, std:
 }
 
 template <typename T>
-int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world, int rank, bool lazy_S) {
+int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world, int rank, bool lazy_S, bool own_only) {
   int64_t nt = (n_unpadded + NB - 1) / NB;
   if (nt < 1) nt = 1;
   w->n = nt * NB;
@@ -1303,6 +1308,18 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
   w->world = world;
   w->rank = rank;
   dense_ldl_layout(nt, world, &w->h_col_off, &w->own_range);
+  w->h_glob_off = w->h_col_off;
+  w->own_only = own_only && world > 1;
+  w->s_tiles = nt * (nt + 1) / 2;
+  if (w->own_only) {
+    // Per-rank ownership: S holds this rank's tile columns only (one contiguous range of the owner-major layout).  The
+    // offset table the kernels use becomes rank-local; the columns of other ranks get a negative offset, which no kernel of
+    // the distributed factorisation dereferences (the assembly writes through per-chunk tables, ba_lm.hip).
+    const int64_t base = w->own_range[(size_t)rank];
+    for (int64_t j = 0; j < nt; j++)
+      w->h_col_off[(size_t)j] = ((j / 2) % world == rank) ? w->h_col_off[(size_t)j] - base : -((int64_t)1 << 40);
+    w->s_tiles = std::max<int64_t>(1, w->own_range[(size_t)rank + 1] - base);
+  }
   BA_HIP_CHECK(hipMalloc((void **)&w->col_off, (size_t)nt * sizeof(int64_t)));
   BA_HIP_CHECK(hipMemcpy(w->col_off, w->h_col_off.data(), (size_t)nt * sizeof(int64_t), hipMemcpyHostToDevice));
   // the tile columns this rank owns (pairs q with q % world == rank), ascending, with running tile counts
@@ -1323,10 +1340,14 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
     w->S = external_S;
     w->own_S = false;
   } else if (!lazy_S) {
-    BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)dense_ldl_tiles_doubles(n_unpadded) * sizeof(T)));
+    BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)w->s_tiles * NB * NB * sizeof(T)));
     w->own_S = true;
   }
   if (!lazy_S) BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(T)));  // 2 x two panels of L*D
+  if (!lazy_S && w->own_only) {
+    BA_HIP_CHECK(hipMalloc((void **)&w->Lb, (size_t)4 * nt * NB * NB * sizeof(T)));  // their L = V D^-1
+    BA_HIP_CHECK(hipMalloc((void **)&w->bpart, (size_t)2 * nt * NB * sizeof(T)));
+  }
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_chain, hipEventDisableTiming | hipEventReleaseToDevice));
   BA_HIP_CHECK(hipMalloc((void **)&w->Linv, (size_t)nt * NB * NB * sizeof(T)));
   // k_ldl_diag writes the lower triangle of each inverse only; the consumers read whole tiles
@@ -1351,10 +1372,12 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
 template <typename T>
 int dense_ldl_alloc_S(DenseLDLT<T> *w) {
   if (!w->S) {
-    BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)(w->nt * (w->nt + 1) / 2) * NB * NB * sizeof(T)));
+    BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)w->s_tiles * NB * NB * sizeof(T)));
     w->own_S = true;
   }
   if (!w->V) BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * w->nt * NB * NB * sizeof(T)));
+  if (!w->Lb && w->own_only) BA_HIP_CHECK(hipMalloc((void **)&w->Lb, (size_t)4 * w->nt * NB * NB * sizeof(T)));
+  if (!w->bpart && w->own_only) BA_HIP_CHECK(hipMalloc((void **)&w->bpart, (size_t)2 * w->nt * NB * sizeof(T)));
   return BA_OK;
 }
 
@@ -1362,6 +1385,8 @@ template <typename T>
 void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->own_S && w->S) (void)hipFree(w->S);
   if (w->V) (void)hipFree(w->V);
+  if (w->Lb) (void)hipFree(w->Lb);
+  if (w->bpart) (void)hipFree(w->bpart);
   if (w->Linv) (void)hipFree(w->Linv);
   if (w->D) (void)hipFree(w->D);
   if (w->flag) (void)hipFree(w->flag);
@@ -1696,8 +1721,14 @@ static int launch_pair_owned(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0,
   if (nblk64 <= 0) return BA_OK;
   const int nblk = (int)nblk64;
   ProfScope ps(p, PC_LDL_UPDATE, st);
+  const T *Lp0 = nullptr, *Lp1 = nullptr;
+  if (w->own_only) {  // the panels' L tiles: the buffer that travels with the V buffer this pair uses
+    Lp0 = w->Lb + (V0 - w->V);
+    Lp1 = w->Lb + (V1 - w->V);
+  }
   hipLaunchKernelGGL((k_ldl_update<T, 1, 0, true>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st,
-                     w->S, w->col_off, V0, V1, k, w->h_own_cols[(size_t)m0], (int)w->nt, nblk, (int *)nullptr, w->own_cols, w->own_pref, m0, m1);
+                     w->S, w->col_off, V0, V1, k, w->h_own_cols[(size_t)m0], (int)w->nt, nblk, (int *)nullptr, w->own_cols, w->own_pref, m0, m1,
+                     1, (const int *)nullptr, Lp0, Lp1);
   return BA_OK;
 }
 
@@ -1731,14 +1762,40 @@ static int dist_transfer(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *V1, in
   if (rc == BA_OK) rc = comm_bcast(p, w->D + (int64_t)k * NB, (int64_t)(two ? 2 : 1) * NB * sizeof(T), owner, st);
   BA_CHECK(comm_group_end(p));
   BA_CHECK(rc);
-  if (owner != w->rank) {
-    if (rows0 > 0)
-      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows0), dim3(256), 0, st, w->S, w->col_off, V0, w->D + (int64_t)k * NB, k, k + 1);
+  if (w->own_only) {
+    // every rank (the owner too: one source for the update's operand) rebuilds L = V D^-1 of both panels in the panel
+    // buffer beside V; nothing of another rank's columns enters S
+    T *L0 = w->Lb + (V0 - w->V), *L1 = w->Lb + (V1 - w->V);
+    if (rows0 > 0) hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows0), dim3(256), 0, st, L0, V0, w->D + (int64_t)k * NB, k + 1);
     if (two && rows1 > 0)
-      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows1), dim3(256), 0, st, w->S, w->col_off, V1, w->D + (int64_t)(k + 1) * NB,
-                         k + 1, k + 2);
+      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows1), dim3(256), 0, st, L1, V1, w->D + (int64_t)(k + 1) * NB, k + 2);
+    BA_HIP_CHECK(hipGetLastError());
+  } else if (owner != w->rank) {
+    if (rows0 > 0)
+      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows0), dim3(256), 0, st, w->S + (w->h_col_off[(size_t)k] - k) * NB * NB, V0,
+                         w->D + (int64_t)k * NB, k + 1);
+    if (two && rows1 > 0)
+      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows1), dim3(256), 0, st, w->S + (w->h_col_off[(size_t)k + 1] - (k + 1)) * NB * NB, V1,
+                         w->D + (int64_t)(k + 1) * NB, k + 2);
     BA_HIP_CHECK(hipGetLastError());
   }
+  return BA_OK;
+}
+
+// per-rank ownership: the forward substitution of the right-hand side rides along with the panels as they arrive -- every
+// rank holds the pair's L tiles (panel buffer) exactly then, and never again.  Replicated: every rank does the same
+// arithmetic on its copy of b.
+template <typename T>
+static int dist_forward_pair(DenseLDLT<T> *w, int k, T *V0, T *V1, T *d_b, hipStream_t st) {
+  if (!d_b) return BA_OK;
+  const int nt = (int)w->nt;
+  T *y = w->D + (int64_t)nt * NB;
+  hipLaunchKernelGGL(k_fwd_step<T>, dim3(nt - k), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k, (const int *)nullptr,
+                     (const T *)(w->Lb + (V0 - w->V)));
+  if (k + 1 < nt)
+    hipLaunchKernelGGL(k_fwd_step<T>, dim3(nt - k - 1), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k + 1, (const int *)nullptr,
+                       (const T *)(w->Lb + (V1 - w->V)));
+  BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
 
@@ -1760,7 +1817,11 @@ static int dist_transfer(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *V1, in
 // transfer q+1 may overwrite Vs[(q+1) & 1] only when update q-1 is through with it (ev_upd), update q+1 starts when
 // transfer q+1 has landed (ev_recv).
 template <typename T>
-int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
+int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, T *d_b) {
+  if (d_b && !w->own_only) {
+    ba_set_error("dense_ldl_factor_dist: the fused forward substitution belongs to the per-rank-ownership layout");
+    return BA_ERR_ARG;
+  }
   const int nt = (int)w->nt, P = w->world, me = w->rank;
   const int64_t panel = (int64_t)nt * NB * NB;
   T *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
@@ -1778,6 +1839,7 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
       const int owner = q % P;
       if (owner == me) BA_CHECK(dist_chain(p, w, k, V0, V1, st));
       BA_CHECK(dist_transfer(p, w, k, V0, V1, owner, st));
+      BA_CHECK(dist_forward_pair(w, k, V0, V1, d_b, st));
       if (k + 2 >= nt) break;
       BA_CHECK(launch_pair_owned(p, w, k, V0, V1, st, own_from(k + 2), M));
     }
@@ -1796,6 +1858,7 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
       T *V0 = Vs[q & 1][0], *V1 = Vs[q & 1][1];
       T *N0 = Vs[(q + 1) & 1][0], *N1 = Vs[(q + 1) & 1][1];
       BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_recv[q & 1], 0));  // pair q's panels are here (join of the transfer stream)
+      BA_CHECK(dist_forward_pair(w, k, V0, V1, d_b, st));  // (ahead of update q, whose event frees this buffer for transfer q+2)
       if (k + 2 >= nt) break;
       const bool next_mine = (q + 1) % P == me;
       int m0 = own_from(k + 2);
@@ -1822,11 +1885,102 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st) {
   return BA_OK;
 }
 
+// ---- backward sweep with per-rank ownership of S ---------------------------------------------------------------------------
+// A rank holds whole tile COLUMNS of L, so the sweep runs column-wise from the last pair to the first: the owner of pair
+// (k, k+1) forms s_c = sum_{i > c} L_ic' x_i for its two columns from x of the later rows (replicated: every rank has
+// received them), x_{k+1} = Linv_{k+1}' (D^-1 y_{k+1} - s_{k+1}), x_k likewise with the coupling tile L_{k+1,k}, and
+// broadcasts the 256 values.  Per pair: one row-parallel kernel (a block per tile below the pair, partial products in a
+// fixed order), one finishing workgroup, one 2 KB broadcast; every rank ends with the same x.  (The forward substitution
+// rode along with the panels, dist_forward_pair.)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bwd_col_part(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ x,
+                                                       T *__restrict__ part, int k, int nt) {
+  // block b: tile row i = k + 2 + b / 2 of column c = k + (b & 1):  part[(c - k) nt + i][:] = L_ic' x_i
+  __shared__ T xi[NB], red[2][NB];
+  const int c = k + (blockIdx.x & 1), i = k + 2 + (blockIdx.x >> 1);
+  const int tid = threadIdx.x, col = tid & (NB - 1), half = tid >> 7;
+  if (tid < NB) xi[tid] = x[(int64_t)i * NB + tid];
+  __syncthreads();
+  const T *L = S + tix(co, i, c) * NB * NB;
+  T s = 0;
+  for (int r = half * 64; r < half * 64 + 64; r++) s += L[r * NB + col] * xi[r];
+  red[half][col] = s;
+  __syncthreads();
+  if (tid < NB) part[((int64_t)(c - k) * nt + i) * NB + tid] = red[0][tid] + red[1][tid];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bwd_col_final(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
+                                                        const T *__restrict__ D, const T *__restrict__ y, const T *__restrict__ part,
+                                                        T *__restrict__ x, int k, int nt) {
+  __shared__ T z[NB], xk1[NB], red[2][NB];
+  const int tid = threadIdx.x, col = tid & (NB - 1), half = tid >> 7;
+  const bool two = k + 1 < nt;
+  auto matvec_t = [&](const T *M, const T *v) {  // red[half][col] = sum over this half's 64 rows of M[r][col] v[r]
+    T s = 0;
+    for (int r = half * 64; r < half * 64 + 64; r++) s += M[r * NB + col] * v[r];
+    red[half][col] = s;
+  };
+  if (two) {  // x_{k+1} = Linv_{k+1}' (y_{k+1} / D_{k+1} - sum_{i > k+1} L_{i,k+1}' x_i)
+    if (tid < NB) {
+      T s = 0;
+      for (int i = k + 2; i < nt; i++) s += part[((int64_t)nt + i) * NB + tid];
+      z[tid] = y[(int64_t)(k + 1) * NB + tid] / D[(int64_t)(k + 1) * NB + tid] - s;
+    }
+    __syncthreads();
+    matvec_t(Linv + (int64_t)(k + 1) * NB * NB, z);
+    __syncthreads();
+    if (tid < NB) {
+      xk1[tid] = red[0][tid] + red[1][tid];
+      x[(int64_t)(k + 1) * NB + tid] = xk1[tid];
+    }
+    __syncthreads();
+    matvec_t(S + tix(co, k + 1, k) * NB * NB, xk1);  // the coupling tile L_{k+1,k}' x_{k+1}
+    __syncthreads();
+  }
+  if (tid < NB) {
+    T s = two ? red[0][tid] + red[1][tid] : (T)0;
+    for (int i = k + 2; i < nt; i++) s += part[(int64_t)i * NB + tid];
+    z[tid] = y[(int64_t)k * NB + tid] / D[(int64_t)k * NB + tid] - s;
+  }
+  __syncthreads();
+  matvec_t(Linv + (int64_t)k * NB * NB, z);
+  __syncthreads();
+  if (tid < NB) x[(int64_t)k * NB + tid] = red[0][tid] + red[1][tid];
+}
+
+template <typename T>
+static int dense_ldl_bwd_dist(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st) {
+  const int nt = (int)w->nt, P = w->world, me = w->rank;
+  const T *y = w->D + (int64_t)nt * NB;
+  const int last = ((nt - 1) / 2) * 2;
+  for (int k = last; k >= 0; k -= 2) {
+    const int owner = (k / 2) % P;
+    const bool two = k + 1 < nt;
+    if (owner == me) {
+      const int below = nt - k - 2;  // tile rows below the pair
+      if (below > 0)
+        hipLaunchKernelGGL(k_bwd_col_part<T>, dim3(2 * below), dim3(256), 0, st, w->S, w->col_off, d_b, w->bpart, k, nt);
+      hipLaunchKernelGGL(k_bwd_col_final<T>, dim3(1), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, w->bpart, d_b, k, nt);
+      BA_HIP_CHECK(hipGetLastError());
+    }
+    BA_CHECK(comm_bcast(p, d_b + (int64_t)k * NB, (int64_t)(two ? 2 : 1) * NB * sizeof(T), owner, st));
+  }
+  return BA_OK;
+}
+
 template <typename T>
 int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool forward_done) {
   const int nt = (int)w->nt;
   T *y = w->D + (int64_t)nt * NB;
   ProfScope ps(p, PC_SOLVE, st);
+  if (w->own_only && p->comm.active()) {
+    if (!forward_done) {
+      ba_set_error("per-rank ownership of S: the forward substitution rides along with the distributed factorisation");
+      return BA_ERR_ARG;
+    }
+    return dense_ldl_bwd_dist(p, w, d_b, st);
+  }
   if (!forward_done)
     for (int k = 0; k < nt; k++)
       hipLaunchKernelGGL(k_fwd_step<T>, dim3(nt - k), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k);
@@ -1929,8 +2083,8 @@ extern "C" int ba_dense_ldl_solve_f32(int device, int64_t n, const double *a_low
   return dense_solve_host<float>(device, n, a_lower_rowmajor, b, x, factor_ms);
 }
 
-template int dense_ldl_alloc<double>(DenseLDLT<double> *, int64_t, double *, int, int, bool);
-template int dense_ldl_alloc<float>(DenseLDLT<float> *, int64_t, float *, int, int, bool);
+template int dense_ldl_alloc<double>(DenseLDLT<double> *, int64_t, double *, int, int, bool, bool);
+template int dense_ldl_alloc<float>(DenseLDLT<float> *, int64_t, float *, int, int, bool, bool);
 template int dense_ldl_alloc_S<double>(DenseLDLT<double> *);
 template int dense_ldl_alloc_S<float>(DenseLDLT<float> *);
 template void dense_ldl_free<double>(DenseLDLT<double> *);
@@ -1939,7 +2093,7 @@ template int dense_ldl_factor<double>(ba_problem *, DenseLDLT<double> *, hipStre
 template int dense_ldl_factor<float>(ba_problem *, DenseLDLT<float> *, hipStream_t, int *, float *);
 template int dense_ldl_use_pattern<double>(DenseLDLT<double> *, const TilePattern *);
 template int dense_ldl_use_pattern<float>(DenseLDLT<float> *, const TilePattern *);
-template int dense_ldl_factor_dist<double>(ba_problem *, DenseLDLT<double> *, hipStream_t);
-template int dense_ldl_factor_dist<float>(ba_problem *, DenseLDLT<float> *, hipStream_t);
+template int dense_ldl_factor_dist<double>(ba_problem *, DenseLDLT<double> *, hipStream_t, double *);
+template int dense_ldl_factor_dist<float>(ba_problem *, DenseLDLT<float> *, hipStream_t, float *);
 template int dense_ldl_solve<double>(ba_problem *, DenseLDLT<double> *, double *, hipStream_t, bool);
 template int dense_ldl_solve<float>(ba_problem *, DenseLDLT<float> *, float *, hipStream_t, bool);

@@ -99,6 +99,13 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   hipEvent_t ev_chain = nullptr;  // recorded behind each hoisted diagonal kernel
   // distributed factorisation with look-ahead: panels of pair q received (transfer stream), update of pair q launched
   hipEvent_t ev_recv[2] = {nullptr, nullptr}, ev_upd[2] = {nullptr, nullptr};
+  // per-rank ownership of S (distributed factorisation): S holds this rank's tile columns only (s_tiles tiles), col_off /
+  // h_col_off are rank-local offsets (negative for other ranks' columns), h_glob_off the owner-major global layout;
+  // Lb: L = V D^-1 of the panel pairs in flight (the layout of V), bpart: partial products of the backward sweep
+  bool own_only = false;
+  int64_t s_tiles = 0;
+  std::vector<int64_t> h_glob_off;
+  T *Lb = nullptr, *bpart = nullptr;
   // block-sparse S (one GPU): the pattern's row / column lists on the device; null pattern = dense
   bool sparse = false;
   const TilePattern *pat = nullptr;
@@ -183,7 +190,8 @@ int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, doubl
 
 // ---- dense LDL^T (ba_dense_ldl.hip) ---------------------------------------------------------------
 template <typename T>
-int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world = 1, int rank = 0, bool lazy_S = false);
+int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int world = 1, int rank = 0, bool lazy_S = false,
+                    bool own_only = false);
 // lazy_S: the tiles of S (and the panel buffers V) are left out until dense_ldl_alloc_S
 template <typename T>
 int dense_ldl_alloc_S(DenseLDLT<T> *w);
@@ -199,7 +207,7 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
 // on entry rank r holds the (summed) tile columns it owns, on exit every rank holds the complete factor (L, Linv, D).
 // No fused forward substitution: call dense_ldl_solve(..., forward_done = false).
 template <typename T>
-int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st);
+int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, T *d_b = nullptr);
 // block-sparse S: symbolic factorisation of the tile occupancy `occ` (nt x nt, lower, row-major; receives the fill) per
 // tile column pair, and its use by a workspace (null: dense).  The pattern object must outlive the workspace.
 void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ, TilePattern *out);

@@ -144,6 +144,7 @@ int build_tasks(ba_problem *p, SchurTasks *T) {
     skey_c0.push_back((int)ct0.size());
     T->nsplit = (int64_t)skey.size();
     T->nchunks = (int64_t)ct0.size();
+    T->h_skey = skey;
     if (T->nsplit > 0) {
       BA_CHECK(upload_vec(&T->skey, skey));
       BA_CHECK(upload_vec(&T->skey_c0, skey_c0));
@@ -152,6 +153,7 @@ int build_tasks(ba_problem *p, SchurTasks *T) {
       BA_CHECK(dmalloc(&T->partial, 81 * T->nchunks));
     }
   }
+  T->h_key_cb = key_cb;
   BA_CHECK(upload_vec(&T->key_ptr, key_ptr));
   BA_CHECK(upload_vec(&T->key_ca, key_ca));
   BA_CHECK(upload_vec(&T->key_cb, key_cb));
@@ -183,6 +185,10 @@ struct LMState {
 
 struct LMWorkFull : LMWork {
   LMState s;
+  std::vector<SchurChunk> chunks;  // per-rank ownership of S: chunks of tile columns, assembled and reduced one by one
+  double *stage = nullptr;         // the chunk being assembled for another owner (stage_tiles tiles)
+  float *stage32 = nullptr;        // its Float32 copy when the reduce travels in Float32
+  int64_t stage_tiles = 0;
   TilePattern pattern;       // tile pattern of S after the symbolic factorisation (ensure_dense)
   bool use_pattern = false;  // the block-sparse list schedule is in use on this handle
   // facto_type = Float32 (src/lm.jl:170-173): Float32 copy of the reduced camera system, allocated on first use
@@ -236,6 +242,12 @@ int launch_convert(const A *in, B *out, int64_t n, hipStream_t st) {
 }
 }  // namespace
 
+// BA_DIST_FACTOR=0: keep the whole reduced camera system on every rank (one all-reduce of S, replicated factorisation)
+static bool dist_factor_on(ba_problem *p) {
+  static const bool off = [] { const char *e = getenv("BA_DIST_FACTOR"); return e && e[0] == '0'; }();
+  return p->comm.active() && !off;
+}
+
 static int ensure_xf32(ba_problem *p, LMWorkFull *w) {
   if (w->xf) return BA_OK;
   BA_HIP_CHECK(hipMalloc((void **)&w->xf, (size_t)(w->nvar > 0 ? w->nvar : 1) * sizeof(float)));
@@ -246,7 +258,8 @@ static int ensure_xf32(ba_problem *p, LMWorkFull *w) {
 
 static int ensure_f32(LMWorkFull *w) {
   if (w->have32) return BA_OK;
-  BA_CHECK(dense_ldl_alloc<float>(&w->ldl32, w->n, nullptr, w->ldl.world, w->ldl.rank));
+  BA_CHECK(dense_ldl_alloc<float>(&w->ldl32, w->n, nullptr, w->ldl.world, w->ldl.rank, false, w->ldl.own_only));
+  if (w->ldl.own_only && !w->stage32) BA_HIP_CHECK(hipMalloc((void **)&w->stage32, (size_t)std::max<int64_t>(1, w->stage_tiles) * NB * NB * sizeof(float)));
   if (w->use_pattern) BA_CHECK(dense_ldl_use_pattern(&w->ldl32, &w->pattern));
   BA_HIP_CHECK(hipMalloc((void **)&w->rhs32, (size_t)w->npad * sizeof(float)));
   w->have32 = true;
@@ -278,7 +291,10 @@ static int lm_ensure(ba_problem *p) {
   // themselves (n^2/2 doubles: 1 GB for Venice, 60 GB for Final-13682), the Schur task list and the per-observation Y blocks
   // are allocated by ensure_dense when a direct solve first needs them: a handle that only ever runs facto = :PCG never
   // holds anything of the size of S.
-  BA_CHECK(dense_ldl_alloc(&w->ldl, w->n, (double *)nullptr, p->comm.active() ? p->comm.world : 1, p->comm.active() ? p->comm.rank : 0, true));
+  // ... and with the distributed factorisation a rank holds ONLY its own tile columns of S (per-rank ownership): the other
+  // ranks' contributions pass through a staging buffer of at most half that size, chunk by chunk (ensure_dense, linear_step)
+  BA_CHECK(dense_ldl_alloc(&w->ldl, w->n, (double *)nullptr, p->comm.active() ? p->comm.world : 1, p->comm.active() ? p->comm.rank : 0, true,
+                           dist_factor_on(p)));
   w->npad = w->ldl.n;
   w->rhs = w->s.red + w->s.off_rhs;
   w->gc = w->s.red + w->s.off_gc;
@@ -310,6 +326,76 @@ static int lm_ensure(ba_problem *p) {
   return BA_OK;
 }
 
+// Per-rank ownership of S: the tile columns of every rank (one contiguous range of the owner-major layout) are cut into
+// chunks of at most about half a rank's share; a chunk is assembled -- by every rank, from its own observations -- either
+// straight into the owner's tiles (the owner itself) or into the staging buffer, and reduced onto the owner.  So no rank
+// ever holds more of S than its own columns plus one chunk: <= 1.5 |S| / world (plus the panel buffers of the
+// factorisation).  A key's 9 x 9 block can straddle two tile columns: it is listed with both chunks and each stores the
+// elements that fall into its own columns (the offset table of the chunk marks the others).
+static int build_chunks(ba_problem *p, LMWorkFull *w) {
+  const DenseLDL &l = w->ldl;
+  const int64_t nt = l.nt;
+  const int P = l.world;
+  const SchurTasks &T = w->tasks;
+  std::vector<int> col_chunk((size_t)nt, -1);
+  std::vector<std::vector<int64_t>> cco;
+  w->chunks.clear();
+  w->stage_tiles = 0;
+  for (int r = 0; r < P; r++) {
+    const int64_t t_begin = l.own_range[(size_t)r], t_end = l.own_range[(size_t)r + 1], share = t_end - t_begin;
+    const int64_t target = std::max<int64_t>(1, (share + 1) / 2);
+    SchurChunk c;
+    c.owner = r;
+    c.t0 = 0;
+    std::vector<int64_t> table((size_t)nt, -((int64_t)1 << 40));
+    int64_t local = 0;  // tile offset inside rank r's own layout
+    auto flush = [&]() {
+      if (c.ntiles == 0) return;
+      w->chunks.push_back(c);
+      cco.push_back(table);
+      if (r != l.rank) w->stage_tiles = std::max(w->stage_tiles, c.ntiles);
+      c = SchurChunk();
+      c.owner = r;
+      c.t0 = local;
+      std::fill(table.begin(), table.end(), -((int64_t)1 << 40));
+    };
+    for (int64_t j = 0; j < nt; j++) {
+      if ((j / 2) % P != r) continue;
+      const int64_t colt = nt - j;
+      if (c.ntiles > 0 && c.ntiles + colt > target) flush();
+      table[(size_t)j] = local - c.t0;  // offset of tile (j, j) inside the chunk's destination buffer
+      col_chunk[(size_t)j] = (int)w->chunks.size();
+      c.ntiles += colt;
+      local += colt;
+    }
+    flush();
+  }
+  // keys per chunk (a block touches tile columns 9 cb / NB and (9 cb + 8) / NB)
+  const size_t nc = w->chunks.size();
+  std::vector<std::vector<int>> keys(nc), skeys(nc);
+  std::vector<int> split_index(T.h_key_cb.size(), -1);
+  for (size_t q = 0; q < T.h_skey.size(); q++) split_index[(size_t)T.h_skey[q]] = (int)q;
+  for (size_t k = 0; k < T.h_key_cb.size(); k++) {
+    const int64_t c0 = 9 * (int64_t)T.h_key_cb[k];
+    const int ch0 = col_chunk[(size_t)(c0 / NB)], ch1 = col_chunk[(size_t)((c0 + 8) / NB)];
+    for (int ch : {ch0, ch1 == ch0 ? -1 : ch1}) {
+      if (ch < 0) continue;
+      if (split_index[k] >= 0) skeys[(size_t)ch].push_back(split_index[k]);
+      else keys[(size_t)ch].push_back((int)k);
+    }
+  }
+  for (size_t c = 0; c < nc; c++) {
+    SchurChunk &ch = w->chunks[c];
+    BA_CHECK(upload_vec(&ch.cco, cco[c]));
+    BA_CHECK(upload_vec(&ch.keys, keys[c]));
+    BA_CHECK(upload_vec(&ch.skeys, skeys[c]));
+    ch.nkeys = (int64_t)keys[c].size();
+    ch.nskeys = (int64_t)skeys[c].size();
+  }
+  BA_HIP_CHECK(hipMalloc((void **)&w->stage, (size_t)std::max<int64_t>(1, w->stage_tiles) * NB * NB * sizeof(double)));
+  return BA_OK;
+}
+
 // what only the direct solves need: the tiles of S, the Schur task list, the per-observation Y blocks
 static int ensure_dense(ba_problem *p, LMWorkFull *w) {
   if (w->ldl.S) return BA_OK;
@@ -326,6 +412,7 @@ static int ensure_dense(ba_problem *p, LMWorkFull *w) {
   const bool want = e ? e[0] != '0' : (w->pattern.flop_fill <= 0.6 && w->ldl.nt >= 8);
   w->use_pattern = want && !p->comm.active();
   if (w->use_pattern) BA_CHECK(dense_ldl_use_pattern(&w->ldl, &w->pattern));
+  if (w->ldl.own_only) BA_CHECK(build_chunks(p, w));
   return BA_OK;
 }
 
@@ -337,6 +424,13 @@ void lm_free(ba_problem *p) {
     dense_ldl_free(&w->ldl32);
     (void)hipFree(w->rhs32);
   }
+  for (SchurChunk &c : w->chunks) {
+    if (c.cco) (void)hipFree(c.cco);
+    if (c.keys) (void)hipFree(c.keys);
+    if (c.skeys) (void)hipFree(c.skeys);
+  }
+  if (w->stage) (void)hipFree(w->stage);
+  if (w->stage32) (void)hipFree(w->stage32);
   if (w->xf) (void)hipFree(w->xf);
   if (w->rf) (void)hipFree(w->rf);
   if (w->Jf) (void)hipFree(w->Jf);
@@ -369,12 +463,6 @@ static int comm_sum(ba_problem *p, LMWorkFull *w, int64_t off, int64_t count, hi
   return comm_allreduce(p, w->s.red + off, count, st);
 }
 
-// BA_DIST_FACTOR=0: keep the whole reduced camera system on every rank (one all-reduce of S, replicated factorisation)
-static bool dist_factor_on(ba_problem *p) {
-  static const bool off = [] { const char *e = getenv("BA_DIST_FACTOR"); return e && e[0] == '0'; }();
-  return p->comm.active() && !off;
-}
-
 // the partial sums of S held by every rank -> the complete tile columns on their owners (distributed factorisation), or
 // the complete S everywhere (replicated); the right-hand side is needed by every rank either way
 // s32: the factorisation will run in Float32 and nothing needs the Float64 sum (no column scaling): every rank rounds its
@@ -384,10 +472,10 @@ static bool dist_factor_on(ba_problem *p) {
 static int reduce_camera_system(ba_problem *p, LMWorkFull *w, hipStream_t st, bool s32 = false) {
   if (!p->comm.active()) return BA_OK;
   if (!dist_factor_on(p)) {  // replicated: the whole S and the right-hand side everywhere
-    BA_CHECK(comm_allreduce(p, w->ldl.S, dense_ldl_tiles_doubles(w->n), st));
+    BA_CHECK(comm_allreduce(p, w->ldl.S, w->ldl.s_tiles * NB * NB, st));
     return comm_sum(p, w, w->s.off_rhs, w->npad, st);
   }
-  if (s32) BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, dense_ldl_tiles_doubles(w->n), st));
+  if (s32) BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, w->ldl.s_tiles * NB * NB, st));
   BA_CHECK(comm_group_begin(p));
   int rc = BA_OK;
   for (int r = 0; r < w->ldl.world && rc == BA_OK; r++) {
@@ -545,35 +633,61 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
     BA_HIP_CHECK(hipMemcpyAsync(dcp, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return launch_backsub(p, Jl, w->Uinv, w->u, dcp, w->delta, st, rl, w->cr0(), w->partial, w->scal, SH_MODEL, &w->model_done);
   }
-  BA_CHECK(launch_schur_blocks(p, &w->tasks, Jl, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
-                               p->rank == 0 ? w->npad : w->n, st, d_lambda, damp));
-  BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
-  BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
   const bool dist = dist_factor_on(p);
   const bool reduce32 = dist && facto_f32 && normalize == 0;
   if (reduce32) BA_CHECK(ensure_f32(w));
-  BA_CHECK(reduce_camera_system(p, w, st, reduce32));
+  if (w->ldl.own_only) {
+    // per-rank ownership of S: chunk by chunk -- this rank's share of the chunk's sums goes straight into its own tiles
+    // when it owns the chunk, else into the staging buffer -- and every chunk is reduced onto its owner at once
+    BA_CHECK(launch_schur_pre(p, &w->tasks, Jl, w->Uinv, w->Yobs, st));
+    for (const SchurChunk &c : w->chunks) {
+      const bool mine = c.owner == w->ldl.rank;
+      double *dest = mine ? w->ldl.S + c.t0 * NB * NB : w->stage;
+      BA_CHECK(launch_schur_chunk(p, &w->tasks, &c, Jl, w->Yobs, w->Hcc, lam_diag, dest, w->n, p->rank == 0 ? w->npad : w->n, st,
+                                  d_lambda, damp));
+      if (reduce32) {  // Float32 factorisation without column scaling: the partial sums travel as Float32
+        float *d32 = mine ? w->ldl32.S + c.t0 * NB * NB : w->stage32;
+        BA_CHECK(launch_convert(dest, d32, c.ntiles * NB * NB, st));
+        BA_CHECK(comm_reduce_f32(p, d32, c.ntiles * NB * NB, c.owner, st));
+      } else {
+        BA_CHECK(comm_reduce(p, dest, c.ntiles * NB * NB, c.owner, st));
+      }
+    }
+    BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
+    BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
+    BA_CHECK(comm_sum(p, w, w->s.off_rhs, w->npad, st));
+  } else {
+    BA_CHECK(launch_schur_blocks(p, &w->tasks, Jl, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
+                                 p->rank == 0 ? w->npad : w->n, st, d_lambda, damp));
+    BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
+    BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
+    BA_CHECK(reduce_camera_system(p, w, st, reduce32));
+  }
   if (normalize != 0) {  // :J / :A column scaling of the camera system from the GLOBAL diagonal (refresh_linearisation)
     BA_CHECK(launch_cam_scale(p, w->hdiag, normalize == 2 ? lambda : 0.0, w->colscale, st, d_lambda));
-    BA_CHECK(launch_scale_S(p, w->n, w->ldl.nt, w->colscale, w->ldl.S, w->ldl.col_off, st));
+    if (w->ldl.own_only)
+      BA_CHECK(launch_scale_S_own(p, w->n, w->colscale, w->ldl.S, w->ldl.col_off, w->ldl.own_cols, w->ldl.own_pref,
+                                  (int)w->ldl.h_own_cols.size(), w->ldl.own_range[(size_t)w->ldl.rank + 1] - w->ldl.own_range[(size_t)w->ldl.rank], st));
+    else
+      BA_CHECK(launch_scale_S(p, w->n, w->ldl.nt, w->colscale, w->ldl.S, w->ldl.col_off, st));
     BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));
   }
   w->last_f32 = facto_f32;
   if (facto_f32) {  // round the assembled system to Float32, factor and solve there, widen the solution
     BA_CHECK(ensure_f32(w));
-    if (!reduce32) BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, dense_ldl_tiles_doubles(w->n), st));
+    if (!reduce32) BA_CHECK(launch_convert(w->ldl.S, w->ldl32.S, w->ldl.s_tiles * NB * NB, st));
     BA_CHECK(launch_convert(w->rhs, w->rhs32, w->npad, st));
     if (dist) {
-      BA_CHECK(dense_ldl_factor_dist<float>(p, &w->ldl32, st));
-      BA_CHECK(dense_ldl_solve<float>(p, &w->ldl32, w->rhs32, st, false));
+      BA_CHECK(dense_ldl_factor_dist<float>(p, &w->ldl32, st, w->ldl32.own_only ? w->rhs32 : (float *)nullptr));
+      BA_CHECK(dense_ldl_solve<float>(p, &w->ldl32, w->rhs32, st, w->ldl32.own_only));
     } else {
       BA_CHECK(dense_ldl_factor<float>(p, &w->ldl32, st, nullptr, w->rhs32));
       BA_CHECK(dense_ldl_solve<float>(p, &w->ldl32, w->rhs32, st, true));
     }
     BA_CHECK(launch_convert(w->rhs32, w->rhs, w->npad, st));
   } else if (dist) {
-    BA_CHECK(dense_ldl_factor_dist(p, &w->ldl, st));
-    BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st, false));
+    BA_CHECK(dense_ldl_factor_dist(p, &w->ldl, st, w->ldl.own_only ? w->rhs : (double *)nullptr));
+    BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st, w->ldl.own_only));
   } else {
     BA_CHECK(dense_ldl_factor(p, &w->ldl, st, nullptr, w->rhs));  // forward substitution of rhs rides along
     BA_CHECK(dense_ldl_solve(p, &w->ldl, w->rhs, st, true));
@@ -777,6 +891,18 @@ static int lm_step_impl(ba_problem *p, const double *x, double lambda, double *d
   if (half_sq_model) *half_sq_model = 0.5 * w->s.h_sh[SH_MODEL];
   if (cg_iters) *cg_iters = (int)w->n_cg;
   w->pcg = false;
+  return BA_OK;
+}
+
+extern "C" int ba_lm_schur_memory(ba_problem *p, int64_t *tiles_full, int64_t *tiles_held, int64_t *tiles_staging) {
+  if (!p || !p->lm || !static_cast<LMWorkFull *>(p->lm)->ldl.S) {
+    ba_set_error("ba_lm_schur_memory: no direct solve has run on this handle yet");
+    return BA_ERR_ARG;
+  }
+  LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
+  if (tiles_full) *tiles_full = w->ldl.nt * (w->ldl.nt + 1) / 2;
+  if (tiles_held) *tiles_held = w->ldl.s_tiles;
+  if (tiles_staging) *tiles_staging = w->ldl.own_only ? w->stage_tiles : 0;
   return BA_OK;
 }
 

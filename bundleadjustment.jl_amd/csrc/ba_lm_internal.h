@@ -21,6 +21,17 @@ struct SchurTasks {
   int *chunk_t0 = nullptr, *chunk_t1 = nullptr;                   // chunks: task range
   double *partial = nullptr;                                      // nchunks x 81
   std::vector<unsigned char> tile_occ;                            // host: nt x nt lower tile occupancy of S by the keys (before fill)
+  std::vector<int> h_key_cb, h_skey;                              // host copies (chunked assembly of a distributed run)
+};
+
+// one chunk of tile columns of the reduced camera matrix in a distributed run with per-rank ownership of S: the columns
+// [owner's local tile range t0 .. t0 + ntiles), the keys whose 9 x 9 blocks touch them, its offset table (negative: not here)
+struct SchurChunk {
+  int owner = 0;
+  int64_t t0 = 0, ntiles = 0;
+  int64_t *cco = nullptr;  // device, nt entries
+  int *keys = nullptr, *skeys = nullptr;  // device: key ids / indices into the split-key list
+  int64_t nkeys = 0, nskeys = 0;
 };
 
 // scalar slots of LMWork::scal (device) / h_scal (pinned host)
@@ -57,6 +68,12 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
 int launch_col_sq(ba_problem *p, const double *d_Hpp, const double *d_hdiag, double *d_jn2, hipStream_t st);
 int launch_f16_scale(ba_problem *p, double lambda, double mu, const double *d_jn2, const double *d_J, const double *d_r,
                      double *d_dcol, double *d_damp, double *d_Jq, double *d_rq, hipStream_t st);
+int launch_schur_pre(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y, hipStream_t st);
+int launch_schur_chunk(ba_problem *p, const SchurTasks *T, const SchurChunk *c, const double *d_J, const double *d_Y,
+                       const double *d_Hcc, double lambda, double *dest, int64_t n, int64_t npad, hipStream_t st,
+                       const double *d_lambda = nullptr, const double *d_damp = nullptr);
+int launch_scale_S_own(ba_problem *p, int64_t n, const double *d_dsc, double *d_S, const int64_t *d_col_off, const int *d_own_cols,
+                       const int64_t *d_own_pref, int ncols, int64_t ntiles, hipStream_t st);
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
                      hipStream_t st, const int *d_cam_pnt = nullptr);
 int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,

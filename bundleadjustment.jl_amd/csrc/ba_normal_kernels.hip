@@ -351,6 +351,7 @@ __global__ __launch_bounds__(BLK) void k_schur_prep(int64_t npnts, double lambda
 // (lower triangle, packed NB x NB tiles).
 __device__ inline void s_store(double *S, const int64_t *__restrict__ co, int64_t gr, int64_t gc, double v) {
   int64_t ti = gr / NB, tj = gc / NB;
+  if (co[tj] < 0) return;  // (chunked assembly of a distributed run: this tile column belongs to another chunk)
   S[(tix(co, ti, tj) * NB + (gr - ti * NB)) * NB + (gc - tj * NB)] = v;
 }
 
@@ -467,7 +468,9 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
                                                        const double *__restrict__ Hcc, double lambda,
                                                        const double *__restrict__ lam_dev, double *__restrict__ S,
                                                        const int64_t *__restrict__ co, const double *__restrict__ damp_c,
-                                                       int split_above) {
+                                                       int split_above, const int *__restrict__ klist = nullptr) {
+  // klist (per-rank ownership of S): the keys whose blocks touch the tile columns of the chunk being assembled; nkeys is
+  // then the length of that list
   __shared__ double stage[BLK / 64][2][48];
   if (lam_dev) lambda *= lam_dev[0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -478,7 +481,8 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
   // re-read from that XCD's L2 -- 4.3 -> 5.1 ms on Venice in round 1's kernel, 3.73 -> 3.67 ms in this one: the L2-miss traffic
   // (9.5 GB per launch against 3.4 GB if every row were fetched once per XCD that needs it) is served by the MALL and does not
   // bound the kernel; the interleaved order stays.)
-  for (int64_t key = (int64_t)blockIdx.x * (BLK / 64) + wv; key < nkeys; key += (int64_t)gridDim.x * (BLK / 64)) {
+  for (int64_t kq = (int64_t)blockIdx.x * (BLK / 64) + wv; kq < nkeys; kq += (int64_t)gridDim.x * (BLK / 64)) {
+    const int64_t key = klist ? klist[kq] : kq;
     const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
     if (split_above > 0 && t_end - t_begin > split_above) continue;
     const d4s acc = schur_accumulate(t_begin, t_end, task_a, task_b, J, Y, stage[wv]);
@@ -518,10 +522,12 @@ __global__ __launch_bounds__(BLK) void k_schur_combine(int64_t nsplit, const int
                                                         const int *__restrict__ key_ca, const int *__restrict__ key_cb,
                                                         const double *__restrict__ partial, const double *__restrict__ Hcc,
                                                         double lambda, const double *__restrict__ lam_dev, double *__restrict__ S,
-                                                        const int64_t *__restrict__ co, const double *__restrict__ damp_c) {
+                                                        const int64_t *__restrict__ co, const double *__restrict__ damp_c,
+                                                        const int *__restrict__ slist = nullptr) {
   if (lam_dev) lambda *= lam_dev[0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int64_t q = (int64_t)blockIdx.x * (BLK / 64) + wv; q < nsplit; q += (int64_t)gridDim.x * (BLK / 64)) {
+  for (int64_t sq = (int64_t)blockIdx.x * (BLK / 64) + wv; sq < nsplit; sq += (int64_t)gridDim.x * (BLK / 64)) {
+    const int64_t q = slist ? slist[sq] : sq;  // slist: the split keys of the chunk being assembled
     const int key = skey[q], c0 = skey_c0[q], c1 = skey_c0[q + 1];
     const int ca = key_ca[key], cb = key_cb[key];
     for (int e = lane; e < 81; e += 64) {
@@ -1193,6 +1199,73 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
     }
   }
   if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S, d_col_off);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+// Chunked assembly (per-rank ownership of S on several ranks): launch_schur_pre once per step -- the per-observation Y
+// blocks and the partial sums of the split keys -- then launch_schur_chunk per chunk of tile columns into `dest` (this
+// rank's own tiles, or the staging buffer whose content is reduced onto the chunk's owner), through the chunk's offset table.
+int launch_schur_pre(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y, hipStream_t st) {
+  ProfScope ps(p, PC_SCHUR_S, st);
+  if (p->nobs > 0)
+    hipLaunchKernelGGL(k_obs_y, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->pnt0, d_J, d_Uinv, d_Y);
+  if (T->nsplit > 0) {
+    int64_t nbc = (T->nchunks + BLK / 64 - 1) / (BLK / 64);
+    if (nbc > (int64_t)1 << 22) nbc = (int64_t)1 << 22;
+    hipLaunchKernelGGL(k_schur_chunks, dim3((unsigned)nbc), dim3(BLK), 0, st, T->nchunks, T->chunk_t0, T->chunk_t1, T->task_a,
+                       T->task_b, d_J, d_Y, T->partial);
+  }
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_schur_chunk(ba_problem *p, const SchurTasks *T, const SchurChunk *c, const double *d_J, const double *d_Y,
+                       const double *d_Hcc, double lambda, double *dest, int64_t n, int64_t npad, hipStream_t st,
+                       const double *d_lambda, const double *d_damp) {
+  ProfScope ps(p, PC_SCHUR_S, st);
+  BA_HIP_CHECK(hipMemsetAsync(dest, 0, (size_t)c->ntiles * NB * NB * sizeof(double), st));
+  const double *damp_c = d_damp ? d_damp + 3 * p->npnts : (const double *)nullptr;
+  if (c->nkeys > 0) {
+    int64_t nb = (c->nkeys + BLK / 64 - 1) / (BLK / 64);
+    if (nb > (int64_t)1 << 22) nb = (int64_t)1 << 22;
+    hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nb), dim3(BLK), 0, st, c->nkeys, T->key_ptr, T->key_ca, T->key_cb, T->task_a,
+                       T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, dest, c->cco, damp_c, T->nsplit > 0 ? 2 * T->chunk : 0, c->keys);
+  }
+  if (c->nskeys > 0) {
+    int64_t nbs = (c->nskeys + BLK / 64 - 1) / (BLK / 64);
+    if (nbs > (int64_t)1 << 22) nbs = (int64_t)1 << 22;
+    hipLaunchKernelGGL(k_schur_combine, dim3((unsigned)nbs), dim3(BLK), 0, st, c->nskeys, T->skey, T->skey_c0, T->key_ca, T->key_cb,
+                       T->partial, d_Hcc, lambda, d_lambda, dest, c->cco, damp_c, c->skeys);
+  }
+  if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, dest, c->cco);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+// S_ij /= d_i d_j on the tile columns a rank owns (own_cols / own_pref as k_ldl_update's OWN mode; block = one tile)
+__global__ __launch_bounds__(BLK) void k_scale_S_own(int64_t n, const double *__restrict__ dsc, double *__restrict__ S,
+                                                      const int64_t *__restrict__ co, const int *__restrict__ own_cols,
+                                                      const int64_t *__restrict__ own_pref, int ncols) {
+  const int64_t t = blockIdx.x;
+  int lo = 0, hi = ncols;  // largest m with own_pref[m] <= t
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (own_pref[mid] <= t) lo = mid;
+    else hi = mid;
+  }
+  const int64_t tj = own_cols[lo], ti = tj + (t - own_pref[lo]);
+  double *T = S + tix(co, ti, tj) * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += BLK) {
+    const int64_t r = ti * NB + (e >> 7), c = tj * NB + (e & (NB - 1));
+    const double dr = r < n ? dsc[r] : 1.0, dc = c < n ? dsc[c] : 1.0;
+    T[e] /= dr * dc;
+  }
+}
+int launch_scale_S_own(ba_problem *p, int64_t n, const double *d_dsc, double *d_S, const int64_t *d_col_off, const int *d_own_cols,
+                       const int64_t *d_own_pref, int ncols, int64_t ntiles, hipStream_t st) {
+  if (ntiles <= 0 || ncols <= 0) return BA_OK;
+  hipLaunchKernelGGL(k_scale_S_own, dim3((unsigned)ntiles), dim3(BLK), 0, st, n, d_dsc, d_S, d_col_off, d_own_cols, d_own_pref, ncols);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }

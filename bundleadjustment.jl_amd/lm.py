@@ -140,3 +140,11 @@ def schur_pattern(nlp):
     tf, ff, sp = C.c_double(0), C.c_double(0), C.c_int(0)
     _lib.check(_lib.lib().ba_lm_schur_pattern(nlp.handle, C.byref(tf), C.byref(ff), C.byref(sp)))
     return tf.value, ff.value, bool(sp.value)
+
+
+def schur_memory(nlp):
+    """(tiles_full, tiles_held, tiles_staging) of a handle that has run a direct solve (ba_lm_schur_memory): the 128 x 128
+    tiles of the whole reduced camera matrix, what this handle holds of it, and its staging buffer (distributed runs)."""
+    a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.lib().ba_lm_schur_memory(nlp.handle, C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value

@@ -226,6 +226,12 @@ int ba_lm_step_pcg(ba_problem *p, const double *x, double lambda, double tol, in
  * off).  tile_fill: pattern tiles (with fill) / all lower tiles; flop_fill: trailing-update tiles of the pattern / of the
  * dense factorisation; sparse_schedule: 1 when the list schedule is in use.  Valid after the first direct solve. */
 int ba_lm_schur_pattern(ba_problem *p, double *tile_fill, double *flop_fill, int *sparse_schedule);
+/* What a handle holds of the reduced camera matrix, in 128 x 128 tiles of its scalar type (Float64; a Float32 factorisation
+ * adds half of that again): tiles_full = the whole lower triangle, nt (nt + 1) / 2; tiles_held = what this handle allocated
+ * for S; tiles_staging = the staging buffer of the chunked assembly.  One GPU (and BA_DIST_FACTOR=0): held = full,
+ * staging = 0.  Distributed factorisation: a rank holds its own tile columns only (about full / world) plus a staging
+ * chunk of at most half of that -- per-rank ownership of S.  Valid after the first direct solve. */
+int ba_lm_schur_memory(ba_problem *p, int64_t *tiles_full, int64_t *tiles_held, int64_t *tiles_staging);
 
 /* ---- per-kernel timing (hipEvent pairs on the handle's stream) ------------------------------------ */
 int ba_profile_enable(ba_problem *p, int on);

@@ -172,6 +172,16 @@ def test_loopback_sharded_step_equals_one_rank(ba, loopback, world):
         ep = rel_err(dp, d_ref)
         assert ep <= 1e-8, f"{world} ranks, facto = :PCG: relative step difference {ep:.3e} (limit 1e-8)"
         assert loopback.ba_loopback_ops(R.loop) > 0
+        # per-rank ownership of S: a rank holds its own tile columns (about 1 / world of the triangle: whole column pairs, so
+        # up to one pair more than the even share) plus a staging chunk of at most about half of that
+        for r, m in enumerate(R.models):
+            full, held, staging = ba.schur_memory(m)
+            nt = 15
+            slack = 2 * nt  # one tile column pair
+            assert full == nt * (nt + 1) // 2
+            assert held <= full / world + slack, f"rank {r}: holds {held} of {full} tiles ({world} ranks)"
+            assert staging <= 0.5 * (full / world + slack) + nt, f"rank {r}: staging {staging} tiles, own share {held}"
+            assert held + staging <= 1.5 * full / world + 2 * slack, f"rank {r}: {held} + {staging} tiles against 1.5 x {full} / {world}"
     finally:
         R.close()
 
@@ -205,4 +215,46 @@ def test_loopback_lookahead_same_bits_as_alternating(ba, loopback, ncams, npnts,
             assert not rep, rep
     finally:
         _set_lookahead(True)
+        R.close()
+
+
+def test_loopback_lm_runs_equal_one_rank(ba, loopback):
+    """Complete LM runs on 3 ranks of one process over the loopback transport (per-rank ownership of S, distributed
+    factorisation and backward sweep, chunked assembly): lm.jl with and without column scaling -- the scaling uses the
+    all-reduced diagonal of J'J and touches only the tiles a rank owns -- give the one-rank run's iterations, status and
+    objective."""
+    prob = ba.synthetic.make_problem(70, 500, 2400, seed=8)  # n = 630: 5 tile rows, pairs owned 0, 1, 2
+    ref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob))
+    want = {}
+    for norm in ("None", "J", "A"):
+        want[norm] = ba.Levenberg_Marquardt(ba.FeasibilityResidual(ref), "LDL", "AMD", norm, False)
+    ref.close()
+    _set_lookahead(True)
+    R = _Ranks(ba, loopback, prob, 3)
+    try:
+        for norm in ("None", "J", "A"):
+            out, err = [None] * 3, [None] * 3
+
+            def run(r, norm=norm):
+                try:
+                    out[r] = ba.Levenberg_Marquardt(ba.FeasibilityResidual(R.models[r]), "LDL", "AMD", norm, False)
+                except Exception as e:  # noqa: BLE001
+                    err[r] = e
+
+            ts = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            assert not any(err), f"normalize {norm}: {err}"
+            w = want[norm]
+            for r in range(3):
+                st = out[r]
+                assert st.iter == w.iter and st.status == w.status, f"normalize {norm}, rank {r}: {st.iter} {st.status} vs {w.iter} {w.status}"
+                assert abs(st.objective - w.objective) <= 1e-9 * w.objective, f"normalize {norm}, rank {r}: {st.objective!r} vs {w.objective!r}"
+            cam = [out[r].solution[-9 * prob["ncams"]:] for r in range(3)]
+            for r in (1, 2):
+                rep = bits_report(cam[0], cam[r], f"normalize {norm}: cameras of rank 0 vs rank {r}")
+                assert not rep, rep
+    finally:
         R.close()
