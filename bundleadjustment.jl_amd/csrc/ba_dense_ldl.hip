@@ -192,6 +192,90 @@ __device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T 
       if (myd == (T)0) *flag = 1;
     }
   };
+  // Float64 (round 3): the same 16 x 16 factorisation with the rank-1 updates of a block batched four at a time into ONE
+  // v_mfma_f64_16x16x4_f64.  The wave holds the block in the matrix instruction's own accumulator layout -- lane
+  // (i = l & 15, g = l >> 4) keeps the four entries A[i][g + 4 reg] of row i -- so a panel of four columns (4p .. 4p+3) IS
+  // register p of the 64 lanes, already in the A / B operand layout [row = l & 15][k = l >> 4].  Per panel: the four panel
+  // entries of every row are gathered into all four lanes of the row (one trip through the wave's LDS scratch), four scalar
+  // steps touch the panel's own columns only (pivot and pivot column by v_readlane, as in the rank-1 form, but at most three
+  // updates per step instead of fifteen), and one MFMA subtracts sum_k X[:,k] (X[:,k] / d_k)' from every column right of
+  // the panel (A operand zeroed for the rows <= 4p+3: in the symmetric accumulator that leaves the columns already factored
+  // untouched; rows above the diagonal carry garbage, unused, as before).  The sums differ from the rank-1 order in the last
+  // bits only.  Measured (tools/bench_diag.py): pivot phases 18.9 -> 15.4 us, tile 51.3 -> 47.8 us; what is left per step is
+  // the dependent chain itself -- v_readlane, v_rcp_f64, two Newton steps, multiply, one FMA: ~200 cycles at ~20 per dependent
+  // Float64 operation (v_rcp_f64 alone is good to 4.6e-8, one Newton step to 20 ulp, two to the last bit:
+  // tools/probes/rcp_f64.hip).  Two variants measured slower than the rank-1 form (51.3 us) and dropped: no gather, the two
+  // cross-lane values of every step by ds_bpermute (55.8 us: four LDS crossbar trips per step sit on the chain); and the
+  // sixteen reciprocals kept in an array indexed by the lane group (53.8 us: the compiler puts it in scratch memory).
+  auto pivots_mfma = [&](int jb) {
+    const int o = 16 * jb;
+    const int i = lane & 15, g = lane >> 4;
+    T *scr = l16;  // free until this block's multipliers are written at the end (row_solves(jb - 1) is behind a barrier)
+    d4 R;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) R[reg] = a[(o + i) * LDA2 + o + g + 4 * reg];
+    // inv_own[pp]: 1 / d of MY column of panel pp (column 4 pp + g), picked up as the steps go by
+    T inv_own[4] = {0, 0, 0, 0}, myd = 0, myinv = 0;
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      scr[i * L16S + g] = R[pp];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      T P[4];
+      {
+        const d2 p01 = *reinterpret_cast<const d2 *>(scr + i * L16S), p23 = *reinterpret_cast<const d2 *>(scr + i * L16S + 2);
+        P[0] = p01[0];
+        P[1] = p01[1];
+        P[2] = p23[0];
+        P[3] = p23[1];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int c = 4 * pp + k;
+        const T d = bcast_lane<T>(P[k], c);  // A[c][c]: row c's copy of the panel (lane c)
+        const T inv = fast_recip<T>(d);
+        if (g == k) inv_own[pp] = inv;
+        if (i == c) {
+          myd = d;
+          myinv = inv;
+        }
+        const T t = P[k] * inv;
+#pragma unroll
+        for (int k2 = k + 1; k2 < 4; k2++) P[k2] -= t * bcast_lane<T>(P[k], 4 * pp + k2);
+      }
+      {
+        T sel = P[0];
+        if (g == 1) sel = P[1];
+        if (g == 2) sel = P[2];
+        if (g == 3) sel = P[3];
+        R[pp] = sel;
+      }
+      if (pp < 3) {
+        const T aop = (i > 4 * pp + 3) ? -R[pp] : (T)0;
+        const T bop = R[pp] * inv_own[pp];
+        R = RT<T>::mfma(aop, bop, R);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the scratch rows are rewritten by the next panel's gather
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lane (i, g) holds X[i][c], c = g + 4 reg: the unscaled entries go back to the tile image, the scaled copy to l16
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      const int c = g + 4 * reg;
+      if (c < i) a[(o + i) * LDA2 + o + c] = R[reg];
+      l16[i * L16S + c] = (c < i) ? R[reg] * inv_own[reg] : (T)0;
+    }
+    if (g == 0) {
+      dd[o + i] = myd;
+      dinv[o + i] = myinv;
+      if (myd == (T)0) *flag = 1;
+    }
+  };
   // X = A(:,jb) L16^-T for the rows below the diagonal block by forward substitution, one row per thread (the rows
   // are independent; X = L D stays unscaled).
   auto row_solves = [&](int jb) {
@@ -242,7 +326,11 @@ __device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T 
   // (tools/bench_diag.py prints a fingerprint of the outputs; 63.1 -> 58.1 us, with the row solves above 53.4 us).
   // (Tried and dropped: one accumulator per k-slice in block_update and in the inverse below -- four independent MFMA
   // chains instead of one dependent chain: slower, 60 us; the chain is not what these phases wait for.)
-  if (wv == 0) pivots(0);
+  auto do_pivots = [&](int jb) {
+    if constexpr (sizeof(T) == 8) pivots_mfma(jb);  // (the Float32 matrix instruction has another accumulator layout: rank-1 form)
+    else pivots(jb);
+  };
+  if (wv == 0) do_pivots(0);
   __syncthreads();
   STAMP(1)
   row_solves(0);
@@ -253,7 +341,7 @@ __device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T 
     __syncthreads();
     STAMP(3)
     if (wv == 0) {
-      pivots(jb + 1);
+      do_pivots(jb + 1);
     } else {  // blocks (I, J), jb + 2 <= J <= I < 8, dealt to waves 1..3
       const int mb = 6 - jb, nblk = mb * (mb + 1) / 2;
       for (int t = wv - 1; t < nblk; t += 3) {

@@ -5,7 +5,7 @@ ba, L = _benchlib.load()
 cyc = (C.c_double * 6)(); ms = C.c_double(0)
 L.ba_debug_diag_stamps.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
 rc = L.ba_debug_diag_stamps(cyc, C.byref(ms))
-names = ["load", "pivots16 (x8)", "inverse16 (x8)", "trsm16+syrk16 (x8)", "full inverse", "store"]
+names = ["load", "pivots16 (x8)", "row solves (x8)", "block updates (x8)", "inverses (8 x 16x16 + full)", "store"]
 tot = sum(cyc)
 print(f"rc {rc}: kernel {ms.value*1e3:.1f} us (unstamped run); stamped cycles (100 MHz memtime ticks?):")
 for n, c in zip(names, cyc): print(f"  {n:22s} {c:10.0f}  {100*c/tot:5.1f}%")
