@@ -252,7 +252,10 @@ def main():
             nt = (9 * ncams + 127) // 128
             # N > 1: the factorisation is distributed, a rank updates the tile columns it owns (pairs q with q % N == rank)
             own = [j for j in range(nt) if (j // 2) % world == rank]
-            tiles = sum(sum(nt - j for j in own if j >= k + 2) for k in range(0, nt - 2, 2))
+            # (single GPU: updates of at most BA_LDL_UPDATE_RS_MAX = 320 tiles take the row-split kernel, its own class)
+            rs_max = int(os.environ.get("BA_LDL_UPDATE_RS_MAX", "320")) if world == 1 else 0
+            per_launch = [sum(nt - j for j in own if j >= k + 2) for k in range(0, nt - 2, 2)]
+            tiles = sum(t for t in per_launch if t > rs_max)
             flops = n_fact * tiles * 2 * 2.0 * 128 ** 3
             ach = flops / (ms * 1e-3) / 1e12
             peak_tf = MFMA_F64_PEAK_TF if args.facto_type == "f64" else MFMA_F32_PEAK_TF

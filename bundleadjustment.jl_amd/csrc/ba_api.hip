@@ -17,7 +17,7 @@ void ba_set_error(const char *fmt, ...) {
 
 const char *const kProfNames[PC_COUNT] = {
     "k_residual", "k_jac_structure", "k_jac_coord", "k_point_blocks", "k_cam_blocks", "k_schur_prep",
-    "k_schur_blocks", "k_schur_rhs", "k_ldl_diag", "k_ldl_trsm", "k_ldl_col", "k_ldl_update", "k_tri_solve",
+    "k_schur_blocks", "k_schur_rhs", "k_ldl_diag", "k_ldl_trsm", "k_ldl_col", "k_ldl_update", "k_ldl_update_rs", "k_tri_solve",
     "k_backsub", "k_model_sq", "k_reduce", "allreduce"};
 
 extern "C" const char *ba_last_error(void) { return g_err; }

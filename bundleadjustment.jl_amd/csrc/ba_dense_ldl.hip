@@ -829,6 +829,52 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int
   }
 }
 
+// rows [32 rq, 32 rq + 32) of one tile of the pair update, S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' (grid = 4 nblk): the
+// row-split form of k_ldl_update<1> for SHORT updates.  A tile of the big kernel is bound by the matrix pipe of the four
+// waves that own it -- 1024 MFMAs per wave, ~30 us, however empty the chip is -- so an update of a few hundred tiles (the
+// block-sparse schedule's, Dubrovnik-356's, LadyBug-49's, the tail of Venice's) takes ~45 us for a fraction of a round.  Here
+// a tile is four workgroups of 32 rows (256 MFMAs per wave), three of them resident per CU.  The same tile enumeration as
+// k_ldl_update (triangular index, optional row list of the block-sparse pattern); the whole K range of each panel is
+// requested up front (tile_gemm_rows).  (Tried in round 3 and dropped for these short updates: running the rest of the update
+// on a second stream beside the next diagonal tile -- the fork / join costs what it hides: 19.17 against 18.95 ms per LM
+// iteration on the Venice shape with 24 % block fill.)
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_update_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
+                                                        const T *__restrict__ V1, int k, int base, int nblk,
+                                                        const int *__restrict__ rows) {
+  BA_VT
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  T *sA = lds, *sB = lds + 2 * RS * LDK;
+  const int t = blockIdx.x >> 2, r0 = (blockIdx.x & 3) * RS;
+  if (t >= nblk) return;
+  int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+  while (ii * (ii + 1) / 2 > t) ii--;
+  const int jj = t - ii * (ii + 1) / 2;
+  const int i = rows ? rows[ii] : base + ii, j = rows ? rows[jj] : base + jj;
+  typename RT<T>::v4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  tile_gemm_rows<T, false>(V0 + (int64_t)i * NB * NB + r0 * NB, S + tix(co, j, k) * NB * NB, sA, sB, acc, nullptr, nullptr);
+  tile_gemm_rows<T, false>(V1 + (int64_t)i * NB * NB + r0 * NB, S + tix(co, j, k + 1) * NB * NB, sA, sB, acc, nullptr, nullptr);
+  const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) * 32;
+  T *Sij = S + tix(co, i, j) * NB * NB + r0 * NB;
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const int col = wc + 16 * n + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = 16 * m + RT<T>::row(lane, g);
+        Sij[row * NB + col] -= acc[m][n][g];
+      }
+  }
+}
+
 // ---- fused panel-pair kernels (pair schedule) ------------------------------------------------------------------------------
 // The panel chain of a pair (k, k+1) -- diag(k), panel solve of column k, update of column k+1, diag(k+1), panel solve of
 // column k+1 -- has only TWO steps that are inherently sequential workgroup-sized jobs, the two diagonal tiles, and the
@@ -1300,7 +1346,8 @@ __global__ __launch_bounds__(256) void k_bwd_step(const T *__restrict__ S, const
 // L2-resident tiles); block 0 stores them, block j+1 applies both panels to y_j, j < k-1.
 template <typename T>
 __global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
-                                                   const T *__restrict__ D, T *__restrict__ y, T *__restrict__ x, int k) {
+                                                   const T *__restrict__ D, T *__restrict__ y, T *__restrict__ x, int k,
+                                                   const int *__restrict__ cols = nullptr) {
   __shared__ T zk[NB], xk[NB], xk1[NB], part[2][NB];
   const int tid = threadIdx.x;
   const int c = tid & (NB - 1), half = tid >> 7;
@@ -1333,7 +1380,8 @@ __global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const
     }
     return;
   }
-  const int j = blockIdx.x - 1;  // 0 .. k-2
+  // cols (block-sparse S): the tile columns in the pattern of row k or row k-1 (a tile outside the pattern holds zeros)
+  const int j = cols ? cols[blockIdx.x - 1] : blockIdx.x - 1;  // 0 .. k-2
   const T *Lkj = S + tix(co, k, j) * NB * NB, *Lk1j = S + tix(co, k - 1, j) * NB * NB;
   T s = 0;
   for (int r = half * 64; r < half * 64 + 64; r++) s += Lkj[r * NB + c] * xk[r] + Lk1j[r * NB + c] * xk1[r];
@@ -1366,6 +1414,8 @@ static int set_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PT_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_pairtrsm<T, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PT_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_rs<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RS_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 0, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_priv_lds_bytes<T>()));
   g_attr_done.store(true);
@@ -1485,6 +1535,7 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->ready) (void)hipFree(w->ready);
   if (w->prow) (void)hipFree(w->prow);
   if (w->lcol) (void)hipFree(w->lcol);
+  if (w->lpair) (void)hipFree(w->lpair);
   if (w->hoist) (void)hipStreamDestroy(w->hoist);
   if (w->ev_top) (void)hipEventDestroy(w->ev_top);
   if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
@@ -1537,13 +1588,25 @@ static int launch_col(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0, hipStr
 
 // pair update of the lower tiles (i, j), base <= j <= i, with panels k, k+1; `ready`: flag raised when tile (base, base)
 // is final (hoisted-diagonal schedule)
+// tiles up to which the pair update takes its row-split form (BA_LDL_UPDATE_RS_MAX; 0 disables)
+static int update_rs_max() {
+  static const int v = [] { const char *e = getenv("BA_LDL_UPDATE_RS_MAX"); return e ? atoi(e) : 320; }();
+  return v;
+}
+
 template <typename T>
 static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, const T *V0, const T *V1, hipStream_t st,
                        int *ready = nullptr, int ready_tiles = 1) {
   const int nt = (int)w->nt, m = nt - base;
   if (m <= 0) return BA_OK;
-  ProfScope ps(p, PC_LDL_UPDATE, st);
   const int nblk = m * (m + 1) / 2;
+  if (!ready && nblk <= update_rs_max()) {  // short update: row-split form (see k_ldl_update_rs)
+    ProfScope ps(p, PC_LDL_UPDATE_RS, st);
+    hipLaunchKernelGGL(k_ldl_update_rs<T>, dim3(4 * nblk), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, V0, V1, k, base, nblk,
+                       (const int *)nullptr);
+    return BA_OK;
+  }
+  ProfScope ps(p, PC_LDL_UPDATE, st);
   // (Cutting the tiles of a partly filled last round into 64 x 64 quadrants, one workgroup each, was tried and removed:
   // 34.1-34.3 ms against 33.9-34.1 at n = 16 002.  A partial round does not cost a full one -- the quadrant kernel took
   // 39 us on average, which is what the big kernel's own last round costs.)
@@ -1718,6 +1781,14 @@ void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ /* nt x nt, 
       }
     out->lcol_ptr.push_back((int)out->lcol.size());
   }
+  // backward sweep two tile rows per launch (rows k, k-1 for k = nt-1, nt-3, ...): the union of their pattern columns < k-1
+  out->lpair_ptr.assign(1, 0);
+  out->lpair.clear();
+  for (int64_t k = nt - 1; k >= 1; k -= 2) {
+    for (int64_t j = 0; j < k - 1; j++)
+      if (occ[(size_t)(k * nt + j)] || occ[(size_t)((k - 1) * nt + j)]) out->lpair.push_back((int)j);
+    out->lpair_ptr.push_back((int)out->lpair.size());
+  }
   out->tile_fill = (double)(ntiles + nt) / ((double)nt * (double)(nt + 1) / 2);
   out->flop_fill = tiles_dense > 0 ? tiles_sparse / tiles_dense : 1.0;
 }
@@ -1726,7 +1797,8 @@ template <typename T>
 int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {
   if (w->prow) (void)hipFree(w->prow);
   if (w->lcol) (void)hipFree(w->lcol);
-  w->prow = w->lcol = nullptr;
+  if (w->lpair) (void)hipFree(w->lpair);
+  w->prow = w->lcol = w->lpair = nullptr;
   w->pat = pat;
   w->sparse = pat != nullptr;
   if (!pat) return BA_OK;
@@ -1734,6 +1806,8 @@ int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {
   BA_HIP_CHECK(hipMalloc((void **)&w->lcol, (pat->lcol.size() + 1) * sizeof(int)));
   if (!pat->prow.empty()) BA_HIP_CHECK(hipMemcpy(w->prow, pat->prow.data(), pat->prow.size() * sizeof(int), hipMemcpyHostToDevice));
   if (!pat->lcol.empty()) BA_HIP_CHECK(hipMemcpy(w->lcol, pat->lcol.data(), pat->lcol.size() * sizeof(int), hipMemcpyHostToDevice));
+  BA_HIP_CHECK(hipMalloc((void **)&w->lpair, (pat->lpair.size() + 1) * sizeof(int)));
+  if (!pat->lpair.empty()) BA_HIP_CHECK(hipMemcpy(w->lpair, pat->lpair.data(), pat->lpair.size() * sizeof(int), hipMemcpyHostToDevice));
   return BA_OK;
 }
 
@@ -1784,11 +1858,15 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
                            w->Linv + (int64_t)(k + 1) * NB * NB, w->D + (int64_t)(k + 1) * NB, V1, k + 1, d_b, y, rows2);
     }
     {
-      ProfScope ps(p, PC_LDL_UPDATE, st);
       const int nblk = c2 * (c2 + 1) / 2;
-      hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S,
-                         w->col_off, V0, V1, k, k + 2, nt, nblk, (int *)nullptr, (const int *)nullptr, (const int64_t *)nullptr, 0, 0,
-                         1, rows2);
+      ProfScope ps(p, nblk <= update_rs_max() ? PC_LDL_UPDATE_RS : PC_LDL_UPDATE, st);
+      if (nblk <= update_rs_max())
+        hipLaunchKernelGGL(k_ldl_update_rs<T>, dim3(4 * nblk), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, V0, V1, k, k + 2,
+                           nblk, rows2);
+      else
+        hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S,
+                           w->col_off, V0, V1, k, k + 2, nt, nblk, (int *)nullptr, (const int *)nullptr, (const int64_t *)nullptr, 0, 0,
+                           1, rows2);
     }
   }
   BA_HIP_CHECK(hipGetLastError());
@@ -2078,7 +2156,12 @@ int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool
       ba_set_error("block-sparse reduced camera system: the forward substitution rides along with the factorisation");
       return BA_ERR_ARG;
     }
-    for (int k = nt - 1; k >= 0; k--) {
+    int k = nt - 1;
+    for (int q = 0; k >= 1; k -= 2, q++) {  // tile rows k, k-1 per launch over the union of their pattern columns
+      const int c0 = pat->lpair_ptr[(size_t)q], c1 = pat->lpair_ptr[(size_t)q + 1];
+      hipLaunchKernelGGL(k_bwd_pair<T>, dim3(1 + (c1 - c0)), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, k, w->lpair + c0);
+    }
+    for (; k >= 0; k--) {
       const int c0 = pat->lcol_ptr[(size_t)k], c1 = pat->lcol_ptr[(size_t)k + 1];
       hipLaunchKernelGGL(k_bwd_step<T>, dim3(1 + (c1 - c0)), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, k, w->lcol + c0);
     }

@@ -50,6 +50,7 @@ enum ProfClass {
   PC_LDL_TRSM,
   PC_LDL_SYRK,    // update of the next tile column inside a panel pair (k_ldl_col_rs)
   PC_LDL_UPDATE,  // bulk pair update of the trailing matrix (k_ldl_update)
+  PC_LDL_UPDATE_RS,  // short pair updates in row-split form (k_ldl_update_rs)
   PC_SOLVE,
   PC_BACKSUB,
   PC_TRIAL,
@@ -69,6 +70,7 @@ struct TilePattern {
   int64_t nt = 0;
   std::vector<int> prow_ptr, prow;  // pair q: [k+1] + the tile rows of its pattern (k = 2q), ascending
   std::vector<int> lcol_ptr, lcol;  // tile row i: the tile columns j < i of its pattern, ascending
+  std::vector<int> lpair_ptr, lpair;  // launch q of the paired backward sweep (rows k = nt-1-2q, k-1): union of their columns < k-1
   double tile_fill = 1.0;           // pattern tiles (with fill) / all lower tiles
   double flop_fill = 1.0;           // trailing-update tiles of the pattern / of the dense factorisation
 };
@@ -109,7 +111,7 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   // block-sparse S (one GPU): the pattern's row / column lists on the device; null pattern = dense
   bool sparse = false;
   const TilePattern *pat = nullptr;
-  int *prow = nullptr, *lcol = nullptr;
+  int *prow = nullptr, *lcol = nullptr, *lpair = nullptr;
   hipEvent_t ev_dtop = nullptr, ev_dchain = nullptr;  // distributed factorisation: fork behind the reduce of S, end of the owner's panel chain
 };
 typedef DenseLDLT<double> DenseLDL;
