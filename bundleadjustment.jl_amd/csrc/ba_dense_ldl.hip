@@ -1607,6 +1607,11 @@ static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, const T 
     return BA_OK;
   }
   ProfScope ps(p, PC_LDL_UPDATE, st);
+  // (Round 3, tried and removed: the remainder of a launch beyond its full rounds of 512 tiles sent ahead in row-split form
+  // (k_ldl_update_rs) so that the big kernel runs full rounds only -- Venice 40.2-40.5 -> 41.3-41.5 ms per LM iteration: per
+  // tile the row-split kernel reads its B tiles four times and costs more than the partly filled round it replaces.  The
+  // same slices as the LAST BLOCKS of the big kernel itself put the two bodies' registers together: 288 VGPRs, one
+  // workgroup per CU.)
   // (Cutting the tiles of a partly filled last round into 64 x 64 quadrants, one workgroup each, was tried and removed:
   // 34.1-34.3 ms against 33.9-34.1 at n = 16 002.  A partial round does not cost a full one -- the quadrant kernel took
   // 39 us on average, which is what the big kernel's own last round costs.)
