@@ -198,9 +198,11 @@ def main():
         ba._lib.check(L.ba_jac_coord_dev(nlp.handle, C.c_void_p(x_dev.data_ptr()), C.c_void_p(vals_dev.data_ptr()), sp))
 
     torch.cuda.synchronize()
-    for _ in range(3):
+    for _ in range(10):
         jac()
-    reps = 20
+    # 60 back-to-back launches (round 2: 20, which on a box that has just idled through the host-side set-up above mostly
+    # measured the clock ramp: 61 us per residual launch against 47-49 at steady state, tools/bench_res.py)
+    reps = 60
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     e0.record(stream)
@@ -221,7 +223,7 @@ def main():
     def res():
         ba._lib.check(L.ba_residual_dev(nlp.handle, C.c_void_p(x_dev.data_ptr()), C.c_void_p(r_dev.data_ptr()), sp))
 
-    for _ in range(3):
+    for _ in range(10):
         res()
     barrier()
     e0.record(stream)

@@ -222,6 +222,12 @@ __device__ inline void jac_block(const T X[3], const T P[12], T J[24]) {
 // DBG (tools/bench_jac.py only): 1 = skip the arithmetic, 2 = skip the stores, 4 = no loads, 8 = no LDS transpose.
 constexpr int CPAD = 16;  // precomputed camera rows: 16 elements (one 128-byte line for double), 16-byte aligned
 
+// (Round 3, tried and removed: forming the rows INSIDE the consuming kernel -- its lowest workgroups first, everybody else
+// polling a counter before gathering rows -- to save this 5.6 us launch and its gap.  With the readers counting themselves out
+// so that the last one could reset the counters: 9 770 atomic adds on one address serialise at ~60 ns each, 594 us for a 57 us
+// kernel.  With a counter that only grows and a per-launch target argument: correct and hipGraph-safe only outside recorded
+// sequences, and 2 us SLOWER than the two launches back to back (49.2 against 47.3 us per residual at steady state,
+// tools/bench_res.py): the wait costs more than the gap it removes.)
 // x's camera block (9 per camera) -> cam_pre rows.  Besides hoisting the per-camera arithmetic, the padded rows make
 // the gather five or six aligned 16-byte loads of ONE cache line per lane instead of nine 8-byte loads straddling two.
 template <typename T>
