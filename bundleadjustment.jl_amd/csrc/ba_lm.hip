@@ -974,6 +974,15 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     ba_set_error("ba_lm_solve: facto = :PCG runs in Float64 (facto_type = Float16 belongs to the :LDL branch)");
     return BA_ERR_ARG;
   }
+  if (o->facto == 2 && o->normalize != 0) {
+    ba_set_error("ba_lm_solve: facto = :PCG has its own scaling (block-Jacobi preconditioner): normalize must be :None");
+    return BA_ERR_ARG;
+  }
+  if (o->facto == 2 && o->facto_type == 1 && !o->x_f32) {
+    ba_set_error("ba_lm_solve: facto = :PCG runs in Float64; facto_type = Float32 belongs to the direct branches "
+                 "(for a Float32 model it is the default and is ignored by :PCG)");
+    return BA_ERR_ARG;
+  }
   if (o->facto_type < 0 || o->facto_type > 2) {
     ba_set_error("ba_lm_solve: facto_type must be 0 (eltype(x)), 1 (Float32) or 2 (Float16)");
     return BA_ERR_ARG;

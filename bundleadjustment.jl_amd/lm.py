@@ -82,6 +82,10 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
         ft = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.float16): 2}[np.dtype(facto_type)]
     if ft == 2 and _FACTO[facto] != 0:
         raise ValueError("facto_type = Float16 exists in the :LDL branch only (src/lm.jl:92-95)")
+    if facto == "PCG" and normalize != "None":
+        raise ValueError("facto = :PCG has its own scaling (block-Jacobi preconditioner): normalize must be :None")
+    if facto == "PCG" and facto_type is not None and ft == 1 and not xf32:
+        raise ValueError("facto = :PCG runs in Float64: facto_type = Float32 belongs to the direct branches")
 
     def d(v):
         return -1.0 if v is None else float(v)

@@ -130,7 +130,8 @@ typedef struct ba_lm_opts {
                    *    2 :PCG (an extension, no counterpart in the reference: SURVEY 8f) -- the reduced camera system is
                    *    never formed; block-Jacobi preconditioned conjugate gradients apply it through J (two sweeps per
                    *    iteration) to |residual| <= pcg_tol |right-hand side|: an inexact LM step, judged by the same
-                   *    accept test; Float64, no column scaling, model value as :QR */
+                   *    accept test; Float64, no column scaling, model value as :QR.  normalize != :None and an explicit
+                   *    facto_type = Float32 on a Float64 model are refused (BA_ERR_ARG), not ignored */
   int normalize;  /* 0 :None, 1 :J, 2 :A  (src/lma_aux.jl:102-178) */
   int linesearch; /* lm.jl only, src/lm.jl:264-295 */
   int facto_type; /* lm.jl only, `facto_type` keyword: 0 = Float64 (the default for a Float64 model), 1 = Float32

@@ -21,6 +21,8 @@ function _ba_lm(model, variant :: Int, facto :: Symbol, perm :: Symbol, normaliz
   # :PCG is an extension of the HIP path (no counterpart in the reference): matrix-free conjugate gradients on the reduced
   # camera system, include/ba_hip.h, ba_lm_opts.facto
   facto in (:QR, :LDL, :PCG) || error("facto must be :QR, :LDL or :PCG")
+  (facto == :PCG && normalize != :None) && error("facto = :PCG has its own scaling (block-Jacobi preconditioner): normalize must be :None")
+  (facto == :PCG && facto_type == Float32 && T != Float32) && error("facto = :PCG runs in Float64: facto_type = Float32 belongs to the direct branches")
   perm in (:AMD, :Metis) || error("perm must be :AMD or :Metis")   # kept for the signature: the device elimination order is fixed
   normalize in (:None, :J, :A) || error("normalize must be :None, :J or :A")
   nlp = model.nlp                       # the BALNLPModel inside FeasibilityResidual (src/solve_ba.jl:25)

@@ -883,6 +883,17 @@ def test_lm_pcg_run_reaches_the_direct_minimum(ba, small_prob, gpu_ok):
         assert abs(st.objective - ref.objective) <= 1e-5 * ref.objective
     with pytest.raises(Exception):
         ba.Levenberg_Marquardt(fr, "PCG", "AMD", "None", False, facto_type=np.float16)
+    # :PCG refuses what it would otherwise silently ignore: column scaling, an explicit Float32 factorisation type
+    with pytest.raises(ValueError):
+        ba.Levenberg_Marquardt(fr, "PCG", "AMD", "J", False)
+    with pytest.raises(ValueError):
+        ba.Levenberg_Marquardt(fr, "PCG", "AMD", "None", False, facto_type=np.float32)
+    o = ba._lib.LMOpts(variant=1, facto=2, normalize=1, linesearch=0, facto_type=0, ite_max=-1, verbose=0, x_f32=0, restol=-1, satol=-1,
+                       srtol=-1, oatol=-1, ortol=-1, atol=-1, rtol=-1, nu_d=-1, nu_m=-1, lam=-1, delta_d=-1, max_time=-1, pcg_tol=-1,
+                       pcg_max_iter=-1)
+    st_c, x_c = ba._lib.LMStats(), np.array(p["x0"], dtype=np.float64)
+    import ctypes as _C
+    assert ba._lib.lib().ba_lm_solve(m.handle, _C.byref(o), ba._lib.ptr(x_c), _C.byref(st_c), _C.cast(None, ba._lib.LOG_CB), None) == 1  # BA_ERR_ARG
     m.close()
 
 
