@@ -377,7 +377,10 @@ def main():
         }
         if FACTO != "PCG":
             tf, ff, sp = ba.schur_pattern(nlp)
-            out["schur_pattern"] = {"tile_fill": tf, "update_tiles_over_dense": ff, "list_schedule": sp}
+            full, held, staging = ba.schur_memory(nlp)
+            out["schur_pattern"] = {"tile_fill": tf, "update_tiles_over_dense": ff, "list_schedule": sp,
+                                    "tiles_full": full, "tiles_held": held, "tiles_staging": staging,
+                                    "S_gib_held": held * 128 * 128 * 8 / 2 ** 30}
         if reducer is not None:
             out["comm"] = {"transport": "rccl (called from the library)" if args.backend == "nccl" else "hook over " + args.backend,
                            "calls": reducer.calls, "bytes": reducer.bytes,

@@ -1362,7 +1362,11 @@ __global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const
   __syncthreads();
   if (tid < NB) xk[tid] = part[0][tid] + part[1][tid];
   __syncthreads();
-  matvec_t(S + tix(co, k, k - 1) * NB * NB, xk);  // L_{k,k-1}' x_k
+  {
+    const int64_t tkk = tix(co, k, k - 1);  // (compressed block-sparse storage: a tile outside the pattern does not exist)
+    if (tkk >= 0) matvec_t(S + tkk * NB * NB, xk);  // L_{k,k-1}' x_k
+    else part[half][c] = 0;
+  }
   __syncthreads();
   if (tid < NB) {
     const T d = D[(int64_t)(k - 1) * NB + tid];
@@ -1382,9 +1386,16 @@ __global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const
   }
   // cols (block-sparse S): the tile columns in the pattern of row k or row k-1 (a tile outside the pattern holds zeros)
   const int j = cols ? cols[blockIdx.x - 1] : blockIdx.x - 1;  // 0 .. k-2
-  const T *Lkj = S + tix(co, k, j) * NB * NB, *Lk1j = S + tix(co, k - 1, j) * NB * NB;
+  const int64_t tkj = tix(co, k, j), tk1j = tix(co, k - 1, j);
+  const T *Lkj = S + tkj * NB * NB, *Lk1j = S + tk1j * NB * NB;
   T s = 0;
-  for (int r = half * 64; r < half * 64 + 64; r++) s += Lkj[r * NB + c] * xk[r] + Lk1j[r * NB + c] * xk1[r];
+  if (tkj >= 0 && tk1j >= 0) {
+    for (int r = half * 64; r < half * 64 + 64; r++) s += Lkj[r * NB + c] * xk[r] + Lk1j[r * NB + c] * xk1[r];
+  } else if (tkj >= 0) {
+    for (int r = half * 64; r < half * 64 + 64; r++) s += Lkj[r * NB + c] * xk[r];
+  } else if (tk1j >= 0) {
+    for (int r = half * 64; r < half * 64 + 64; r++) s += Lk1j[r * NB + c] * xk1[r];
+  }
   part[half][c] = s;
   __syncthreads();
   if (tid < NB) y[(int64_t)j * NB + tid] -= D[(int64_t)j * NB + tid] * (part[0][tid] + part[1][tid]);
@@ -1445,8 +1456,9 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
   w->nt = nt;
   w->world = world;
   w->rank = rank;
-  dense_ldl_layout(nt, world, &w->h_col_off, &w->own_range);
-  w->h_glob_off = w->h_col_off;
+  dense_ldl_layout(nt, world, &w->h_glob_off, &w->own_range);
+  w->h_col_tab.assign((size_t)nt + 1, 0);  // head 0: dense layout
+  for (int64_t j = 0; j < nt; j++) w->hco()[j] = w->h_glob_off[(size_t)j];
   w->own_only = own_only && world > 1;
   w->s_tiles = nt * (nt + 1) / 2;
   if (w->own_only) {
@@ -1455,11 +1467,12 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
     // the distributed factorisation dereferences (the assembly writes through per-chunk tables, ba_lm.hip).
     const int64_t base = w->own_range[(size_t)rank];
     for (int64_t j = 0; j < nt; j++)
-      w->h_col_off[(size_t)j] = ((j / 2) % world == rank) ? w->h_col_off[(size_t)j] - base : -((int64_t)1 << 40);
+      w->hco()[j] = ((j / 2) % world == rank) ? w->hco()[j] - base : BA_NO_TILE;
     w->s_tiles = std::max<int64_t>(1, w->own_range[(size_t)rank + 1] - base);
   }
-  BA_HIP_CHECK(hipMalloc((void **)&w->col_off, (size_t)nt * sizeof(int64_t)));
-  BA_HIP_CHECK(hipMemcpy(w->col_off, w->h_col_off.data(), (size_t)nt * sizeof(int64_t), hipMemcpyHostToDevice));
+  BA_HIP_CHECK(hipMalloc((void **)&w->col_tab, w->h_col_tab.size() * sizeof(int64_t)));
+  BA_HIP_CHECK(hipMemcpy(w->col_tab, w->h_col_tab.data(), w->h_col_tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  w->col_off = w->col_tab + 1;
   // the tile columns this rank owns (pairs q with q % world == rank), ascending, with running tile counts
   w->h_own_cols.clear();
   w->h_own_pref.assign(1, 0);
@@ -1528,7 +1541,7 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->Linv) (void)hipFree(w->Linv);
   if (w->D) (void)hipFree(w->D);
   if (w->flag) (void)hipFree(w->flag);
-  if (w->col_off) (void)hipFree(w->col_off);
+  if (w->col_tab) (void)hipFree(w->col_tab);
   if (w->own_cols) (void)hipFree(w->own_cols);
   if (w->own_pref) (void)hipFree(w->own_pref);
   if (w->flag_sum) (void)hipFree(w->flag_sum);
@@ -1551,7 +1564,7 @@ void dense_ldl_free(DenseLDLT<T> *w) {
 template <typename T>
 static int launch_diag(ba_problem *p, DenseLDLT<T> *w, int k, hipStream_t st, const int *wait_ready = nullptr) {
   ProfScope ps(p, PC_LDL_DIAG, st);
-  hipLaunchKernelGGL(k_ldl_diag<T>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(T), st, w->S + tix(w->h_col_off.data(), k, k) * NB * NB,
+  hipLaunchKernelGGL(k_ldl_diag<T>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(T), st, w->S + tix(w->hco(), k, k) * NB * NB,
                      w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag, (unsigned long long *)nullptr,
                      wait_ready);
   return BA_OK;
@@ -1807,6 +1820,40 @@ int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {
   w->pat = pat;
   w->sparse = pat != nullptr;
   if (!pat) return BA_OK;
+  {
+    // Compressed storage: only the tiles of the pattern are allocated.  Column j (pair q = j / 2, k = 2q) stores the tile rows
+    // j, k+1 (even j), U_q, in that order; the table behind the column offsets gives every (i, j) its position (tix).
+    const int64_t nt = w->nt;
+    std::vector<int64_t> tab((size_t)(1 + nt + nt * nt), BA_NO_TILE);
+    tab[0] = nt;
+    int64_t *co = tab.data() + 1, *rp = tab.data() + 1 + nt;
+    int64_t off = 0;
+    for (int64_t j = 0; j < nt; j++) {
+      const int64_t q = j / 2, k = 2 * q;
+      co[j] = off;
+      int64_t pos = 0;
+      rp[j * nt + j] = pos++;
+      const int l0 = pat->prow_ptr[(size_t)q], l1 = pat->prow_ptr[(size_t)q + 1];
+      for (int l = l0; l < l1; l++) {
+        const int64_t i = pat->prow[(size_t)l];  // [k+1] + U_q
+        if (i > j) rp[i * nt + j] = pos++;
+      }
+      (void)k;
+      off += pos;
+    }
+    w->h_col_tab.swap(tab);
+    w->s_tiles = off;
+    if (w->col_tab) (void)hipFree(w->col_tab);
+    w->col_tab = nullptr;
+    BA_HIP_CHECK(hipMalloc((void **)&w->col_tab, w->h_col_tab.size() * sizeof(int64_t)));
+    BA_HIP_CHECK(hipMemcpy(w->col_tab, w->h_col_tab.data(), w->h_col_tab.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    w->col_off = w->col_tab + 1;
+    if (w->S && w->own_S) {  // (a workspace allocated before its pattern was known: Float32 twin)
+      (void)hipFree(w->S);
+      w->S = nullptr;
+      BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)w->s_tiles * NB * NB * sizeof(T)));
+    }
+  }
   BA_HIP_CHECK(hipMalloc((void **)&w->prow, (pat->prow.size() + 1) * sizeof(int)));
   BA_HIP_CHECK(hipMalloc((void **)&w->lcol, (pat->lcol.size() + 1) * sizeof(int)));
   if (!pat->prow.empty()) BA_HIP_CHECK(hipMemcpy(w->prow, pat->prow.data(), pat->prow.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1943,10 +1990,10 @@ static int dist_transfer(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *V1, in
     BA_HIP_CHECK(hipGetLastError());
   } else if (owner != w->rank) {
     if (rows0 > 0)
-      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows0), dim3(256), 0, st, w->S + (w->h_col_off[(size_t)k] - k) * NB * NB, V0,
+      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows0), dim3(256), 0, st, w->S + (w->hco()[k] - k) * NB * NB, V0,
                          w->D + (int64_t)k * NB, k + 1);
     if (two && rows1 > 0)
-      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows1), dim3(256), 0, st, w->S + (w->h_col_off[(size_t)k + 1] - (k + 1)) * NB * NB, V1,
+      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(rows1), dim3(256), 0, st, w->S + (w->hco()[k + 1] - (k + 1)) * NB * NB, V1,
                          w->D + (int64_t)(k + 1) * NB, k + 2);
     BA_HIP_CHECK(hipGetLastError());
   }
@@ -2204,7 +2251,7 @@ static int dense_solve_host(int device, int64_t n, const double *a_lower_rowmajo
     for (int64_t j = 0; j <= i; j++) {
       int64_t tj = j / NB;
       double v = (i < n) ? a_lower_rowmajor[i * n + j] : (i == j ? 1.0 : 0.0);
-      tiles[(size_t)((tix(w.h_col_off.data(), ti, tj) * NB + (i - ti * NB)) * NB + (j - tj * NB))] = (T)v;
+      tiles[(size_t)((tix(w.hco(), ti, tj) * NB + (i - ti * NB)) * NB + (j - tj * NB))] = (T)v;
     }
   }
   std::vector<T> bb((size_t)npad, (T)0);

@@ -31,9 +31,15 @@ void ba_set_error(const char *fmt, ...);
 // (ascending q inside a group), so that the part of S a rank owns in the distributed factorisation is ONE contiguous
 // range (a single reduce onto its owner per rank).  With world == 1 this is plain column order.
 constexpr int NB = 128;
+// Tile (i, j), j <= i, of the packed reduced camera matrix sits at tile offset tix(col_off, i, j).  col_off points ONE PAST the
+// head of its table: col_off[-1] = 0 for the dense layout (a tile column is contiguous: col_off[j] + (i - j)), or = nt for the
+// compressed layout of a block-sparse pattern, where col_off[nt + i nt + j] is the position of tile row i among the stored
+// rows of column j (negative, and so a negative result, for a tile outside the pattern: nothing is allocated for it).
 __host__ __device__ inline int64_t tix(const int64_t *__restrict__ col_off, int64_t i, int64_t j) {
-  return col_off[j] + (i - j);
+  const int64_t n = col_off[-1];
+  return col_off[j] + (n ? col_off[n + i * n + j] : (i - j));
 }
+constexpr int64_t BA_NO_TILE = -((int64_t)1 << 40);
 // host: fill col_off (nt entries) and, when own_range != null, the [begin, end) tile ranges of the `world` owners
 void dense_ldl_layout(int64_t nt, int world, std::vector<int64_t> *col_off, std::vector<int64_t> *own_range);
 
@@ -83,7 +89,10 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   T *Linv = nullptr;       // nt tiles: inverse of each unit-lower diagonal tile
   T *D = nullptr;          // nt*NB pivots (+ nt*NB scratch)
   int64_t *col_off = nullptr;           // device: tile column offsets (see tix)
-  std::vector<int64_t> h_col_off;       // host copy
+  std::vector<int64_t> h_col_tab;       // host copy of the table: [head | nt column offsets | (compressed) nt x nt row positions]
+  int64_t *col_tab = nullptr;           // the device allocation (col_off = col_tab + 1)
+  const int64_t *hco() const { return h_col_tab.data() + 1; }
+  int64_t *hco() { return h_col_tab.data() + 1; }
   std::vector<int64_t> own_range;       // world + 1 tile offsets: rank r owns tiles [own_range[r], own_range[r+1])
   int world = 1, rank = 0;              // distribution of the tile column pairs (owner of pair q: q % world)
   std::vector<int> h_own_cols;          // tile columns owned by this rank, ascending
@@ -102,7 +111,7 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   // distributed factorisation with look-ahead: panels of pair q received (transfer stream), update of pair q launched
   hipEvent_t ev_recv[2] = {nullptr, nullptr}, ev_upd[2] = {nullptr, nullptr};
   // per-rank ownership of S (distributed factorisation): S holds this rank's tile columns only (s_tiles tiles), col_off /
-  // h_col_off are rank-local offsets (negative for other ranks' columns), h_glob_off the owner-major global layout;
+  // hco() are rank-local offsets (negative for other ranks' columns), h_glob_off the owner-major global layout;
   // Lb: L = V D^-1 of the panel pairs in flight (the layout of V), bpart: partial products of the backward sweep
   bool own_only = false;
   int64_t s_tiles = 0;

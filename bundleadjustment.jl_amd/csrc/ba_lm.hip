@@ -347,7 +347,7 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
     SchurChunk c;
     c.owner = r;
     c.t0 = 0;
-    std::vector<int64_t> table((size_t)nt, -((int64_t)1 << 40));
+    std::vector<int64_t> table((size_t)nt, BA_NO_TILE);
     int64_t local = 0;  // tile offset inside rank r's own layout
     auto flush = [&]() {
       if (c.ntiles == 0) return;
@@ -357,7 +357,7 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
       c = SchurChunk();
       c.owner = r;
       c.t0 = local;
-      std::fill(table.begin(), table.end(), -((int64_t)1 << 40));
+      std::fill(table.begin(), table.end(), BA_NO_TILE);
     };
     for (int64_t j = 0; j < nt; j++) {
       if ((j / 2) % P != r) continue;
@@ -386,7 +386,12 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
   }
   for (size_t c = 0; c < nc; c++) {
     SchurChunk &ch = w->chunks[c];
-    BA_CHECK(upload_vec(&ch.cco, cco[c]));
+    {  // (tix reads the head of a table one entry before its pointer: 0 = dense columns)
+      std::vector<int64_t> with_head(cco[c].size() + 1, 0);
+      std::copy(cco[c].begin(), cco[c].end(), with_head.begin() + 1);
+      BA_CHECK(upload_vec(&ch.cco_alloc, with_head));
+      ch.cco = ch.cco_alloc + 1;
+    }
     BA_CHECK(upload_vec(&ch.keys, keys[c]));
     BA_CHECK(upload_vec(&ch.skeys, skeys[c]));
     ch.nkeys = (int64_t)keys[c].size();
@@ -399,7 +404,6 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
 // what only the direct solves need: the tiles of S, the Schur task list, the per-observation Y blocks
 static int ensure_dense(ba_problem *p, LMWorkFull *w) {
   if (w->ldl.S) return BA_OK;
-  BA_CHECK(dense_ldl_alloc_S(&w->ldl));
   BA_CHECK(dmalloc(&w->Yobs, 6 * p->nobs));
   BA_CHECK(build_tasks(p, &w->tasks));
   // Block-sparse reduced camera system (one GPU): symbolic factorisation of the tile occupancy; the list schedule is used
@@ -411,7 +415,8 @@ static int ensure_dense(ba_problem *p, LMWorkFull *w) {
   const char *e = getenv("BA_SPARSE_S");
   const bool want = e ? e[0] != '0' : (w->pattern.flop_fill <= 0.6 && w->ldl.nt >= 8);
   w->use_pattern = want && !p->comm.active();
-  if (w->use_pattern) BA_CHECK(dense_ldl_use_pattern(&w->ldl, &w->pattern));
+  if (w->use_pattern) BA_CHECK(dense_ldl_use_pattern(&w->ldl, &w->pattern));  // (compressed layout: before S is allocated)
+  BA_CHECK(dense_ldl_alloc_S(&w->ldl));
   if (w->ldl.own_only) BA_CHECK(build_chunks(p, w));
   return BA_OK;
 }
@@ -425,7 +430,7 @@ void lm_free(ba_problem *p) {
     (void)hipFree(w->rhs32);
   }
   for (SchurChunk &c : w->chunks) {
-    if (c.cco) (void)hipFree(c.cco);
+    if (c.cco_alloc) (void)hipFree(c.cco_alloc);
     if (c.keys) (void)hipFree(c.keys);
     if (c.skeys) (void)hipFree(c.skeys);
   }
@@ -658,7 +663,7 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
     BA_CHECK(comm_sum(p, w, w->s.off_rhs, w->npad, st));
   } else {
     BA_CHECK(launch_schur_blocks(p, &w->tasks, Jl, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
-                                 p->rank == 0 ? w->npad : w->n, st, d_lambda, damp));
+                                 p->rank == 0 ? w->npad : w->n, st, d_lambda, damp, w->ldl.s_tiles));
     BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
     BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
     BA_CHECK(reduce_camera_system(p, w, st, reduce32));

@@ -29,7 +29,8 @@ struct SchurTasks {
 struct SchurChunk {
   int owner = 0;
   int64_t t0 = 0, ntiles = 0;
-  int64_t *cco = nullptr;  // device, nt entries
+  int64_t *cco = nullptr;  // device, nt entries (cco_alloc + 1: tix reads the table's head one entry before)
+  int64_t *cco_alloc = nullptr;
   int *keys = nullptr, *skeys = nullptr;  // device: key ids / indices into the split-key list
   int64_t nkeys = 0, nskeys = 0;
 };
@@ -63,7 +64,7 @@ int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const d
                       double *d_u, hipStream_t st, const double *d_lambda = nullptr, const double *d_damp = nullptr);
 int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
                         const double *d_Hcc, double lambda, double *d_S, const int64_t *d_col_off, int64_t n, int64_t npad,
-                        hipStream_t st, const double *d_lambda = nullptr, const double *d_damp = nullptr);
+                        hipStream_t st, const double *d_lambda = nullptr, const double *d_damp = nullptr, int64_t s_tiles = 0);
 // facto_type = Float16 (ba_normal_kernels.hip, k_f16_cols): |J_j|^2 of every column; column scaling + Float16 rounding
 int launch_col_sq(ba_problem *p, const double *d_Hpp, const double *d_hdiag, double *d_jn2, hipStream_t st);
 int launch_f16_scale(ba_problem *p, double lambda, double mu, const double *d_jn2, const double *d_J, const double *d_r,

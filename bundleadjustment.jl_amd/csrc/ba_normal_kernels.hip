@@ -352,7 +352,9 @@ __global__ __launch_bounds__(BLK) void k_schur_prep(int64_t npnts, double lambda
 __device__ inline void s_store(double *S, const int64_t *__restrict__ co, int64_t gr, int64_t gc, double v) {
   int64_t ti = gr / NB, tj = gc / NB;
   if (co[tj] < 0) return;  // (chunked assembly of a distributed run: this tile column belongs to another chunk)
-  S[(tix(co, ti, tj) * NB + (gr - ti * NB)) * NB + (gc - tj * NB)] = v;
+  const int64_t tt = tix(co, ti, tj);
+  if (tt < 0) return;  // (compressed storage: cannot happen for a key of the list the pattern was built from)
+  S[(tt * NB + (gr - ti * NB)) * NB + (gc - tj * NB)] = v;
 }
 
 // Y_b = U_p^-1 A_b'  (3x2, row-major) per observation: the point-side half of Q_ab = A_a Y_b
@@ -570,7 +572,9 @@ __global__ __launch_bounds__(BLK) void k_scale_S(int64_t n, int64_t nt, const do
   while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
   while (ti * (ti + 1) / 2 > t) ti--;
   const int64_t tj = t - ti * (ti + 1) / 2;
-  double *T = S + tix(co, ti, tj) * NB * NB;
+  const int64_t tt = tix(co, ti, tj);
+  if (tt < 0) return;  // (compressed block-sparse storage: not in the pattern)
+  double *T = S + tt * NB * NB;
   for (int e = threadIdx.x; e < NB * NB; e += BLK) {
     const int64_t r = ti * NB + (e >> 7), c = tj * NB + (e & (NB - 1));
     const double dr = r < n ? dsc[r] : 1.0, dc = c < n ? dsc[c] : 1.0;
@@ -1176,9 +1180,10 @@ int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const d
 
 int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
                         const double *d_Hcc, double lambda, double *d_S, const int64_t *d_col_off, int64_t n, int64_t npad,
-                        hipStream_t st, const double *d_lambda, const double *d_damp) {
+                        hipStream_t st, const double *d_lambda, const double *d_damp, int64_t s_tiles) {
   ProfScope ps(p, PC_SCHUR_S, st);
-  BA_HIP_CHECK(hipMemsetAsync(d_S, 0, (size_t)dense_ldl_tiles_doubles(n) * sizeof(double), st));
+  // s_tiles: the tiles S holds (the whole lower triangle, or only the pattern's with compressed block-sparse storage)
+  BA_HIP_CHECK(hipMemsetAsync(d_S, 0, (size_t)(s_tiles > 0 ? s_tiles * NB * NB : dense_ldl_tiles_doubles(n)) * sizeof(double), st));
   if (p->nobs > 0)
     hipLaunchKernelGGL(k_obs_y, dim3(grid_for(p->nobs, BLK)), dim3(BLK), 0, st, p->nobs, p->pnt0, d_J, d_Uinv, d_Y);
   if (T->nkeys > 0) {

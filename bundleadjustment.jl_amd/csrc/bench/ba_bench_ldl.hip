@@ -61,9 +61,11 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   const int m = nt - (quad ? 4 : 2), nblk = m * (m + 1) / 2, grid = ((nblk + 7) / 8) * 8;
   std::vector<int64_t> h_co;
   dense_ldl_layout(nt, 1, &h_co, nullptr);
-  int64_t *co = nullptr;
-  BA_HIP_CHECK(hipMalloc((void **)&co, (size_t)nt * sizeof(int64_t)));
-  BA_HIP_CHECK(hipMemcpy(co, h_co.data(), (size_t)nt * sizeof(int64_t), hipMemcpyHostToDevice));
+  int64_t *co_alloc = nullptr, *co = nullptr;  // (tix reads the table's head one entry before its pointer: 0 = dense)
+  h_co.insert(h_co.begin(), 0);
+  BA_HIP_CHECK(hipMalloc((void **)&co_alloc, h_co.size() * sizeof(int64_t)));
+  BA_HIP_CHECK(hipMemcpy(co_alloc, h_co.data(), h_co.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  co = co_alloc + 1;
   hipEvent_t e0, e1;
   BA_HIP_CHECK(hipEventCreate(&e0));
   BA_HIP_CHECK(hipEventCreate(&e1));
@@ -115,7 +117,7 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   *ms_out = ms / reps;
   (void)hipFree(S);
   (void)hipFree(V);
-  (void)hipFree(co);
+  (void)hipFree(co_alloc);
   return BA_OK;
 }
 
@@ -132,9 +134,11 @@ extern "C" int ba_debug_update_seq(int nt, int n, const int *m_list, const int *
   hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)((vel + 255) / 256)), dim3(256), 0, 0, V, vel, fs);
   std::vector<int64_t> h_co;
   dense_ldl_layout(nt, 1, &h_co, nullptr);
-  int64_t *co = nullptr;
-  BA_HIP_CHECK(hipMalloc((void **)&co, (size_t)nt * sizeof(int64_t)));
-  BA_HIP_CHECK(hipMemcpy(co, h_co.data(), (size_t)nt * sizeof(int64_t), hipMemcpyHostToDevice));
+  int64_t *co_alloc = nullptr, *co = nullptr;  // (tix reads the table's head one entry before its pointer: 0 = dense)
+  h_co.insert(h_co.begin(), 0);
+  BA_HIP_CHECK(hipMalloc((void **)&co_alloc, h_co.size() * sizeof(int64_t)));
+  BA_HIP_CHECK(hipMemcpy(co_alloc, h_co.data(), h_co.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  co = co_alloc + 1;
   std::vector<hipEvent_t> ev((size_t)2 * n);
   for (auto &e : ev) BA_HIP_CHECK(hipEventCreate(&e));
   BA_HIP_CHECK(hipDeviceSynchronize());
@@ -167,7 +171,7 @@ extern "C" int ba_debug_update_seq(int nt, int n, const int *m_list, const int *
   for (auto &e : ev) (void)hipEventDestroy(e);
   (void)hipFree(S);
   (void)hipFree(V);
-  (void)hipFree(co);
+  (void)hipFree(co_alloc);
   return BA_OK;
 }
 

@@ -223,14 +223,14 @@ int ba_lm_step_pcg(ba_problem *p, const double *x, double lambda, double tol, in
  * LDL^T exploits that (symbolic phase src/ldl_aux.jl:82-119, numeric :122-201).  The device keeps the sparsity at the
  * granularity of its 128 x 128 tiles: on the first direct solve the tile occupancy of the Schur key list goes through a
  * symbolic factorisation per tile column pair, and when the pattern's trailing updates are at most 60 % of the dense
- * factorisation's, assembly-side zeros are skipped by a list-driven schedule (one GPU; BA_SPARSE_S=1 / 0 forces it on /
- * off).  tile_fill: pattern tiles (with fill) / all lower tiles; flop_fill: trailing-update tiles of the pattern / of the
+ * factorisation's, assembly-side zeros are skipped by a list-driven schedule and only the pattern's tiles are allocated
+ * (one GPU; BA_SPARSE_S=1 / 0 forces it on / off).  tile_fill: pattern tiles (with fill) / all lower tiles; flop_fill: trailing-update tiles of the pattern / of the
  * dense factorisation; sparse_schedule: 1 when the list schedule is in use.  Valid after the first direct solve. */
 int ba_lm_schur_pattern(ba_problem *p, double *tile_fill, double *flop_fill, int *sparse_schedule);
 /* What a handle holds of the reduced camera matrix, in 128 x 128 tiles of its scalar type (Float64; a Float32 factorisation
  * adds half of that again): tiles_full = the whole lower triangle, nt (nt + 1) / 2; tiles_held = what this handle allocated
  * for S; tiles_staging = the staging buffer of the chunked assembly.  One GPU (and BA_DIST_FACTOR=0): held = full,
- * staging = 0.  Distributed factorisation: a rank holds its own tile columns only (about full / world) plus a staging
+ * staging = 0 -- unless the block-sparse list schedule is in use, which allocates the pattern's tiles only.  Distributed factorisation: a rank holds its own tile columns only (about full / world) plus a staging
  * chunk of at most half of that -- per-rank ownership of S.  Valid after the first direct solve. */
 int ba_lm_schur_memory(ba_problem *p, int64_t *tiles_full, int64_t *tiles_held, int64_t *tiles_staging);
 

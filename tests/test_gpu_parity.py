@@ -1001,11 +1001,17 @@ def test_block_sparse_step_vs_oracle(ba, orc, gpu_ok, locality):
         m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
         d, half, _ = ba.lm_step(m, p["x0"], lam, facto_type=facto_type)
         pat = ba.schur_pattern(m)
+        mem.append(ba.schur_memory(m))
         m.close()
         return d, half, pat
 
+    mem = []
     d_s, half_s, pat_s = _with_env("BA_SPARSE_S", "1", run)
     d_d, half_d, pat_d = _with_env("BA_SPARSE_S", "0", run)
+    # compressed storage: the list schedule allocates the pattern's tiles only; the dense schedule the whole triangle
+    (full_s, held_s, _), (full_d, held_d, _) = mem[0], mem[1]
+    assert full_s == full_d == 22 * 23 // 2 and held_d == full_d
+    assert held_s == round(pat_s[0] * full_s), f"list schedule holds {held_s} tiles, pattern says {pat_s[0] * full_s:.1f} of {full_s}"
     d_a, half_a, pat_a = _with_env("BA_SPARSE_S", None, run)
     d32, _, _ = _with_env("BA_SPARSE_S", "1", lambda: run(np.float32))
     print(f"locality {locality}: block fill {block_fill:.3f}, tile fill of the keys {tile_fill0:.3f}, with factor fill "
