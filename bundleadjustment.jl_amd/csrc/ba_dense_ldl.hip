@@ -1603,8 +1603,8 @@ static int launch_col(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0, hipStr
 // is final (hoisted-diagonal schedule)
 // tiles up to which the pair update takes its row-split form (BA_LDL_UPDATE_RS_MAX; 0 disables)
 static int update_rs_max() {
-  static const int v = [] { const char *e = getenv("BA_LDL_UPDATE_RS_MAX"); return e ? atoi(e) : 320; }();
-  return v;
+  const char *e = getenv("BA_LDL_UPDATE_RS_MAX");  // read per call: a test compares the two kernels in one process
+  return e ? atoi(e) : 320;
 }
 
 template <typename T>

@@ -1014,6 +1014,11 @@ def test_block_sparse_step_vs_oracle(ba, orc, gpu_ok, locality):
     assert held_s == round(pat_s[0] * full_s), f"list schedule holds {held_s} tiles, pattern says {pat_s[0] * full_s:.1f} of {full_s}"
     d_a, half_a, pat_a = _with_env("BA_SPARSE_S", None, run)
     d32, _, _ = _with_env("BA_SPARSE_S", "1", lambda: run(np.float32))
+    # the same list schedule with every pair update through the big tile-per-workgroup kernel (row lists + compressed
+    # storage there too) instead of the row-split one these short updates take by default
+    d_big, _, _ = _with_env("BA_LDL_UPDATE_RS_MAX", "0", lambda: _with_env("BA_SPARSE_S", "1", run))
+    e = np.linalg.norm(d_big - d_s) / np.linalg.norm(d_s)
+    assert e <= 1e-11, f"block-sparse schedule, big update kernel vs row-split: {e:.3e}"
     print(f"locality {locality}: block fill {block_fill:.3f}, tile fill of the keys {tile_fill0:.3f}, with factor fill "
           f"{pat_s[0]:.3f}, update tiles / dense {pat_s[1]:.3f}; automatic choice: {'sparse' if pat_a[2] else 'dense'}")
     assert pat_s[2] and not pat_d[2]
