@@ -315,6 +315,7 @@ static int lm_ensure(ba_problem *p) {
   BA_CHECK(dmalloc(&w->Hcc, 45 * ncams));
   BA_CHECK(dmalloc(&w->colscale, 9 * ncams));
   BA_CHECK(dmalloc(&w->partial, std::max<int64_t>(RED_BLOCKS, (npnts + 255) / 256)));  // k_wtv<true>: one partial per 256 points
+  BA_CHECK(dmalloc(&w->partial_multi, (int64_t)4 * RED_BLOCKS));
   BA_HIP_CHECK(hipMalloc((void **)&w->cam_pnt, (size_t)(p->nobs > 0 ? p->nobs : 1) * sizeof(int)));
   BA_CHECK(launch_cam_pnt(p, w->cam_pnt, p->stream));
   BA_CHECK(dmalloc(&w->s.scal_rep, (int64_t)RP_COUNT));
@@ -440,7 +441,7 @@ void lm_free(ba_problem *p) {
   if (w->rf) (void)hipFree(w->rf);
   if (w->Jf) (void)hipFree(w->Jf);
   void *ptrs[] = {w->jn2, w->dcol, w->damp, w->Jq, w->rq, w->x, w->x_trial, w->delta, w->r, w->r_trial, w->J, w->Hpp, w->gp, w->Uinv, w->u, w->Hcc,
-                  w->partial, w->colscale, w->Yobs, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
+                  w->partial, w->partial_multi, w->colscale, w->Yobs, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
                   w->tasks.task_a, w->tasks.task_b, w->tasks.skey, w->tasks.skey_c0, w->tasks.chunk_t0,
                   w->tasks.chunk_t1, w->tasks.partial, w->s.own_red ? w->s.red : nullptr};
   for (void *q : ptrs)
@@ -504,7 +505,6 @@ static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too
   } else if (residual_too) {
     BA_CHECK(launch_residual_f64(p, w->x, w->r, st));
   }
-  BA_CHECK(launch_sumsq(p, w->nequ, w->r, w->partial, w->scal, SH_RSQ, st));
   if (xf32) {
     BA_CHECK(launch_jac_coord_f32(p, w->xf, w->Jf, st));
     BA_CHECK(launch_convert(w->Jf, w->J, 24 * p->nobs, st));
@@ -513,15 +513,24 @@ static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too
   }
   BA_CHECK(launch_point_blocks(p, w->J, w->r, w->Hpp, w->gp, st));
   BA_CHECK(launch_cam_blocks(p, w->J, w->r, w->Hcc, w->gc, st));
-  BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->gp, w->partial, w->scal, SH_GP, st));
-  BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->x, w->partial, w->scal, SH_X_P, st));
+  {  // |r|^2, |gp|^2, |x_points|^2 in one launch pair (bit-identical to three launch_sumsq calls)
+    SumsqJobs jobs;
+    jobs.add(w->r, w->nequ, w->scal, SH_RSQ);
+    jobs.add(w->gp, 3 * p->npnts, w->scal, SH_GP);
+    jobs.add(w->x, 3 * p->npnts, w->scal, SH_X_P);
+    BA_CHECK(launch_sumsq_multi(p, &jobs, w->partial_multi, st));
+  }
   // gc, the diagonal of the camera block (the column scalings need the global one) and the linearisation scalars are
   // adjacent in the reduce buffer: one all-reduce
   BA_CHECK(launch_hcc_diag(p, w->Hcc, w->hdiag, st));
   BA_CHECK(comm_sum(p, w, w->s.off_gc, 2 * w->npad + SH_LIN_COUNT, st));
   if (w->f16) BA_CHECK(launch_col_sq(p, w->Hpp, w->hdiag, w->jn2, st));  // |J_j|^2 before the blocks are overwritten by scaled ones
-  BA_CHECK(launch_sumsq(p, w->n, w->gc, w->partial, w->s.scal_rep, RP_GC, st));
-  BA_CHECK(launch_sumsq(p, w->n, w->x + 3 * p->npnts, w->partial, w->s.scal_rep, RP_X_C, st));
+  {
+    SumsqJobs jobs;
+    jobs.add(w->gc, w->n, w->s.scal_rep, RP_GC);
+    jobs.add(w->x + 3 * p->npnts, w->n, w->s.scal_rep, RP_X_C);
+    BA_CHECK(launch_sumsq_multi(p, &jobs, w->partial_multi, st));
+  }
   return BA_OK;
 }
 
@@ -713,8 +722,12 @@ static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st, double cr 
   if (first) cr = w->cr0();
   if (!(first && w->model_done)) BA_CHECK(launch_model_sq(p, w->J_lin(), w->r_lin(), w->delta, w->partial, w->scal, SH_MODEL, st, cr));
   w->model_done = false;
-  BA_CHECK(launch_sumsq(p, 3 * p->npnts, w->delta, w->partial, w->scal, SH_DELTA_P, st));
-  BA_CHECK(launch_sumsq(p, w->n, w->delta + 3 * p->npnts, w->partial, w->s.scal_rep, RP_DELTA_C, st));
+  {
+    SumsqJobs jobs;
+    jobs.add(w->delta, 3 * p->npnts, w->scal, SH_DELTA_P);
+    jobs.add(w->delta + 3 * p->npnts, w->n, w->s.scal_rep, RP_DELTA_C);
+    BA_CHECK(launch_sumsq_multi(p, &jobs, w->partial_multi, st));
+  }
   return BA_OK;
 }
 

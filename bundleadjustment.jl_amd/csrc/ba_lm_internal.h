@@ -35,6 +35,23 @@ struct SchurChunk {
   int64_t nkeys = 0, nskeys = 0;
 };
 
+// up to four sums of squares in one launch pair (launch_sumsq_multi): vector, length, destination array and slot
+struct SumsqJobs {
+  int count = 0;
+  const double *v[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t n[4] = {0, 0, 0, 0};
+  double *out[4] = {nullptr, nullptr, nullptr, nullptr};
+  int slot[4] = {0, 0, 0, 0};
+  int nb[4] = {0, 0, 0, 0};  // filled by the launcher
+  void add(const double *vec, int64_t len, double *dst, int s) {
+    v[count] = vec;
+    n[count] = len;
+    out[count] = dst;
+    slot[count] = s;
+    count++;
+  }
+};
+
 // scalar slots of LMWork::scal (device) / h_scal (pinned host)
 enum { SC_RSQ = 0, SC_RSQ_TRIAL, SC_MODEL, SC_DELTA, SC_XSQ, SC_JTR, SC_COUNT = 8 };
 
@@ -52,6 +69,7 @@ struct LMWork {
   // facto_type = Float16: |J_j|^2, column norms, damping vector (nvar each), quantised J (24/obs) and r; allocated on first use
   double *jn2 = nullptr, *dcol = nullptr, *damp = nullptr, *Jq = nullptr, *rq = nullptr;
   double *partial = nullptr;             // RED_BLOCKS
+  double *partial_multi = nullptr;       // 4 x RED_BLOCKS (launch_sumsq_multi)
   int *cam_pnt = nullptr;                // nobs: the point of every observation in camera order (pnt0[cam_obs[q]])
   double *scal = nullptr;                // SC_COUNT device scalars
   double *h_scal = nullptr;              // pinned host mirror
@@ -84,6 +102,7 @@ int launch_model_sq(ba_problem *p, const double *d_J, const double *d_r, const d
                     double *d_scal, int slot, hipStream_t st, double cr = 1.0);
 int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial, double *d_scal, int slot,
                  hipStream_t st);
+int launch_sumsq_multi(ba_problem *p, SumsqJobs *jobs, double *d_partial_multi /* 4 RED_BLOCKS */, hipStream_t st);
 int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st);
 int launch_hcc_diag(ba_problem *p, const double *d_Hcc, double *d_hdiag, hipStream_t st);
 int launch_cam_scale(ba_problem *p, const double *d_hdiag, double add, double *d_dsc, hipStream_t st,

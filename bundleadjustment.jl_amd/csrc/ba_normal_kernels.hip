@@ -723,6 +723,36 @@ __global__ __launch_bounds__(BLK) void k_sum_partials(int np, const double *__re
   if (threadIdx.x == 0) out[slot] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// Several sums of squares in ONE launch pair (the LM loop needs |r|^2, |gp|^2, |x_p|^2 ... one after the other: on small
+// problems every one of those two-kernel launches costs more in launch latency than in work).  Vector v owns the blocks
+// [v RED_BLOCKS, v RED_BLOCKS + nb_v) and sums exactly what k_sumsq would with a grid of nb_v blocks; the second kernel is
+// k_sum_partials per vector: the results are bit-identical to the separate launches.
+__global__ __launch_bounds__(BLK) void k_sumsq_multi(SumsqJobs jobs, double *__restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  const int v = blockIdx.x / RED_BLOCKS, b = blockIdx.x % RED_BLOCKS;
+  const int nb = jobs.nb[v];
+  if (b >= nb) return;
+  const double *__restrict__ x = jobs.v[v];
+  const int64_t n = jobs.n[v];
+  double acc = 0;
+  for (int64_t i = (int64_t)b * BLK + threadIdx.x; i < n; i += (int64_t)nb * BLK) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[v * RED_BLOCKS + b] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(BLK) void k_sum_partials_multi(SumsqJobs jobs, const double *__restrict__ partial) {
+  __shared__ double red[BLK / 64];
+  const int v = blockIdx.x;
+  const double *pp = partial + v * RED_BLOCKS;
+  double acc = 0;
+  for (int i = threadIdx.x; i < jobs.nb[v]; i += BLK) acc += pp[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) jobs.out[v][jobs.slot[v]] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 __global__ __launch_bounds__(BLK) void k_axpy(int64_t n, const double *__restrict__ x, const double *__restrict__ d,
                                                double *__restrict__ y) {
   int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
@@ -1362,6 +1392,21 @@ int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial,
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(BLK), 0, st, n, d_v, d_partial);
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLK), 0, st, nb, d_partial, d_scal, slot);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+int launch_sumsq_multi(ba_problem *p, SumsqJobs *jobs, double *d_partial_multi, hipStream_t st) {
+  if (jobs->count <= 0) return BA_OK;
+  ProfScope ps(p, PC_REDUCE, st);
+  for (int v = 0; v < jobs->count; v++) {
+    int nb = (int)((jobs->n[v] + BLK - 1) / BLK);
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    jobs->nb[v] = nb;
+  }
+  hipLaunchKernelGGL(k_sumsq_multi, dim3(jobs->count * RED_BLOCKS), dim3(BLK), 0, st, *jobs, d_partial_multi);
+  hipLaunchKernelGGL(k_sum_partials_multi, dim3(jobs->count), dim3(BLK), 0, st, *jobs, (const double *)d_partial_multi);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
