@@ -64,9 +64,13 @@ constexpr size_t GEMM_LDS_ELEMS = (size_t)(DBUF ? 2 : 1) * 2 * NB * LDK;
 // then the eight 16x16 unit-lower inverses and the full unit-lower inverse of the tile by block forward substitution
 // (MFMA), stored transposed in the upper triangle of the LDS image.  Writes the inverse's lower triangle and D; the
 // factored tile itself is not written back (nothing reads it).
+#ifndef BA_DIAG_EXP
+#define BA_DIAG_EXP 0
+#endif
 constexpr int LDA2 = 130;  // row stride 260 dwords = 4 mod 64: conflict-free MFMA operand reads
 constexpr int XDL = 18;
 constexpr int L16S = 18;   // row stride of the 16x16 multiplier block: 16-byte aligned rows for the row solves' paired reads
+constexpr int DIAG_THREADS = 512;  // k_ldl_diag: eight waves, two per SIMD (see diag_tile)
 constexpr size_t DIAG_LDS_ELEMS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB + 16 * L16S);
 
 // broadcast lane `src` (a compile-time constant after unrolling) of v to the whole wave: v_readlane_b32 into SGPRs
@@ -127,8 +131,8 @@ __device__ inline bool hoisted_wait(const int *wait_ready, int need, int *flag) 
 }
 
 // factor one diagonal tile in the workgroup's LDS image `sm` (DIAG_LDS_ELEMS elements): see the section comment above
-template <typename T>
-__device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T *__restrict__ D_k, int *__restrict__ flag,
+template <typename T, int NW>
+__device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T *__restrict__ D_k, int *__restrict__ flag,
                                  unsigned long long *__restrict__ stamps, T *sm) {
   BA_VT
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;  // diagnostic phase timers (stamps != null only)
@@ -140,22 +144,24 @@ __device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T 
   }
   if (stamps) tlast = __builtin_amdgcn_s_memtime();
   T *a = sm, *xd = sm + NB * LDA2, *dd = xd + 8 * 16 * XDL, *dinv = dd + NB, *l16 = dinv + NB;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keeps the task loops' branches scalar
   const int fr = lane & 15, fk = lane >> 4;
   // tile -> LDS: 16-byte loads, 16 in flight per thread (unpredicated: loads under a per-thread condition serialise).
   // The strict upper triangle of the LDS image is never read before the inverse phase writes it.
+  constexpr int NT = 64 * NW, LQ = NB * NB / 2 / NT / 2;  // threads; 16-byte loads per thread and round
 #pragma unroll
   for (int b0 = 0; b0 < 2; b0++) {
-    d2 v[16];
+    d2 v[LQ];
 #pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = *reinterpret_cast<const d2 *>(Skk + 2 * ((b0 * 16 + q) * 256 + tid));
+    for (int q = 0; q < LQ; q++) v[q] = *reinterpret_cast<const d2 *>(Skk + 2 * ((b0 * LQ + q) * NT + tid));
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const int idx = 2 * ((b0 * 16 + q) * 256 + tid), i = idx >> 7, j = idx & (NB - 1);
+    for (int q = 0; q < LQ; q++) {
+      const int idx = 2 * ((b0 * LQ + q) * NT + tid), i = idx >> 7, j = idx & (NB - 1);
       *reinterpret_cast<d2 *>(a + i * LDA2 + j) = v[q];
     }
   }
-  for (int idx = tid; idx < 8 * 16 * XDL; idx += 256) xd[idx] = 0.0;
+  for (int idx = tid; idx < 8 * 16 * XDL; idx += NT) xd[idx] = 0.0;
   __syncthreads();
   STAMP(0)
   // unblocked LDL' of the 16x16 diagonal block jb in the registers of one wave: lane i holds row i, a pivot and the
@@ -326,6 +332,85 @@ __device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T 
   // (tools/bench_diag.py prints a fingerprint of the outputs; 63.1 -> 58.1 us, with the row solves above 53.4 us).
   // (Tried and dropped: one accumulator per k-slice in block_update and in the inverse below -- four independent MFMA
   // chains instead of one dependent chain: slower, 60 us; the chain is not what these phases wait for.)
+  // The inverse of the tile's unit-lower factor rides along with the factorisation (round 3; before, it was a phase of its
+  // own after the last block column: 11.7 of the tile's 47.5 us, one wave's chain of dependent matrix instructions per
+  // block column, followed by 4.5 us of stores).  X = L^-1, right-looking by block columns of L:
+  //   X(J,J) = L16(J)^-1,   X(I,J) = -L16(I)^-1 acc(I,J),   acc(I,J) = sum_{K=J}^{I-1} L(I,K) X(K,J).
+  // Stage s (block column s of L is final after row_solves(s), L16(s)^-1 comes from one wave beside row_solves(s), which
+  // never occupies more than 112 threads):
+  //   with the update of block column s+1 (7-s blocks): X(s,J) = -L16(s)^-1 acc(s,J), J < s (s blocks) -- seven tasks;
+  //   while wave 0 factors diagonal block s+1: acc(I,J) += L(I,s) X(s,J), I > s, J <= s, dealt to the worker waves with
+  //   the trailing blocks of the factorisation -- 28, 27, 25, 22, 18, 13, 7 independent tasks of four matrix
+  //   instructions each, where the factorisation alone had 21, 15, 10, 6, 3, 1, 0.
+  // acc(I,J) waits in the LDS slot X(I,J) will take (X(I,J)[i][j] at a[16J+j][16I+i]: the strict upper block triangle,
+  // which the factorisation never touches), same lane, same register, and receives its terms in the order K = J, J+1,
+  // ...: the sums are those of the former phase, bit for bit.  Every finished block goes to the Linv tile in global memory
+  // at once: no store phase is left either.  The kernel k_ldl_diag runs this with eight waves (seven workers, two waves
+  // per SIMD so that one's LDS round trips hide behind the other's matrix instructions): 47.5 -> 37.3 us (tools/bench_diag.py).
+  auto inv16 = [&](int jb) {  // lanes 0..15 of one wave, one column each: l[i][m] = a[i][m] * dinv[m]
+    const int o = 16 * jb, c = lane;
+    T *xj = xd + jb * 16 * XDL;
+    // column-oriented: once x[m] is known every later row takes its term -- sixteen dependent steps of one multiply-add
+    // each instead of a chain through all 120 (each row still sums its terms in the order m = 0, 1, ...: same bits)
+    // (the column of step m + 1 and all sixteen 1/d are requested ahead of step m's arithmetic, and the scheduler is kept
+    // from sinking those reads behind the value they would then wait for: without it every step pays an LDS round trip)
+    T sacc[16], di[16], col[16], nxt[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      sacc[i] = 0;
+      di[i] = dinv[o + i];
+      col[i] = (i >= 1) ? a[(o + i) * LDA2 + o] : (T)0;
+      nxt[i] = 0;
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+#pragma unroll
+      for (int i = m + 2; i < 16; i++) nxt[i] = a[(o + i) * LDA2 + o + m + 1];
+      __builtin_amdgcn_sched_barrier(0);
+      const T xv = (m < c) ? 0.0 : (m == c ? 1.0 : -sacc[m]);
+      const T y = xv * di[m];  // dinv[m] * x[m]
+#pragma unroll
+      for (int i = m + 1; i < 16; i++) sacc[i] += col[i] * y;
+      xj[m * XDL + c] = xv;
+      if (!(BA_DIAG_EXP & 4)) Linv_k[(o + m) * NB + o + c] = xv;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = m + 2; i < 16; i++) col[i] = nxt[i];
+    }
+  };
+  auto inv_finalize = [&](int I, int J) {  // X(I,J) = -L16(I)^-1 acc(I,J)
+    d4 acc;
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc[g] = a[(16 * J + fr) * LDA2 + 16 * I + RT<T>::row(lane, g)];
+    d4 out = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 4; g++) out = RT<T>::mfma(xd[(I * 16 + fr) * XDL + RT<T>::row(lane, g)], acc[g], out);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      a[(16 * J + fr) * LDA2 + 16 * I + RT<T>::row(lane, g)] = -out[g];
+      if (!(BA_DIAG_EXP & 4)) Linv_k[(16 * I + RT<T>::row(lane, g)) * NB + 16 * J + fr] = -out[g];
+    }
+  };
+  auto inv_update = [&](int I, int J, int K) {  // acc(I,J) += L(I,K) X(K,J)
+    d4 acc = {0, 0, 0, 0};
+    if (K > J) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc[g] = a[(16 * J + fr) * LDA2 + 16 * I + RT<T>::row(lane, g)];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const int k = 16 * K + 4 * kk + fk;
+      const T af = a[(16 * I + fr) * LDA2 + k] * dinv[k];
+      // X(K,J): the diagonal block's inverse lives in xd, the others transposed in the upper triangle (one address
+      // computation for both: a branch here would split the four matrix instructions into four basic blocks)
+      const T *bp = (K == J) ? xd + (J * 16 + fk) * XDL + fr : a + (16 * J + fr) * LDA2 + 16 * K + fk;
+      const int bstep = (K == J) ? 4 * XDL : 4;
+      acc = RT<T>::mfma(af, bp[kk * bstep], acc);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) a[(16 * J + fr) * LDA2 + 16 * I + RT<T>::row(lane, g)] = acc[g];
+  };
+  constexpr int NWK = NW - 1;  // worker waves 1 .. NW-1
   auto do_pivots = [&](int jb) {
     if constexpr (sizeof(T) == 8) pivots_mfma(jb);  // (the Float32 matrix instruction has another accumulator layout: rank-1 form)
     else pivots(jb);
@@ -334,102 +419,54 @@ __device__ inline void diag_tile(T *__restrict__ Skk, T *__restrict__ Linv_k, T 
   __syncthreads();
   STAMP(1)
   row_solves(0);
+  if (!(BA_DIAG_EXP & 1) && wv == 3 && lane < 16) inv16(0);
   __syncthreads();
   STAMP(2)
   for (int jb = 0; jb < 7; jb++) {
-    for (int I = jb + 1 + wv; I < 8; I += 4) block_update(jb, I, jb + 1);
+    for (int t = wv; t < 7; t += NW) {  // seven tasks: block column jb + 1 of the factorisation, block row jb of the inverse
+      if (t < 7 - jb) block_update(jb, jb + 1 + t, jb + 1);
+      else if (!(BA_DIAG_EXP & 2)) inv_finalize(jb, t - (7 - jb));
+    }
     __syncthreads();
     STAMP(3)
+    unsigned long long c0 = 0;
+    if (stamps) c0 = __builtin_amdgcn_s_memtime();
     if (wv == 0) {
-      do_pivots(jb + 1);
-    } else {  // blocks (I, J), jb + 2 <= J <= I < 8, dealt to waves 1..3
-      const int mb = 6 - jb, nblk = mb * (mb + 1) / 2;
-      for (int t = wv - 1; t < nblk; t += 3) {
-        int ii = 0;
-        while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-        const int jj = t - ii * (ii + 1) / 2;
-        block_update(jb, jb + 2 + ii, jb + 2 + jj);
+      if (!(BA_DIAG_EXP & 8)) do_pivots(jb + 1);
+    } else {
+      // trailing blocks (I, J), jb + 2 <= J <= I < 8, of the factorisation, then the inverse's (I, J), I > jb >= J
+      const int mb = 6 - jb, nblk = mb * (mb + 1) / 2, ninv = (BA_DIAG_EXP & 2) ? 0 : (7 - jb) * (jb + 1);
+      for (int t = wv - 1; t < nblk + ninv; t += NWK) {
+        if (t < nblk) {
+          int ii = 0;
+          while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+          const int jj = t - ii * (ii + 1) / 2;
+          block_update(jb, jb + 2 + ii, jb + 2 + jj);
+        } else {
+          const int e = t - nblk, J = e / (7 - jb), I = jb + 1 + e % (7 - jb);
+          inv_update(I, J, jb);
+        }
       }
     }
+    if (stamps && lane == 0) stamps[6 + jb * 8 + wv] = __builtin_amdgcn_s_memtime() - c0;  // busy time of this wave
     __syncthreads();
     STAMP(1)
     row_solves(jb + 1);
+    if (!(BA_DIAG_EXP & 1) && wv == 3 && lane < 16) inv16(jb + 1);
     __syncthreads();
     STAMP(2)
   }
-  if (tid < 128) {  // the eight 16x16 unit-lower inverses, one column per thread: l[i][m] = a[i][m] * dinv[m]
-    const int o = 16 * (tid >> 4), c = tid & 15;
-    T *xj = xd + (tid >> 4) * 16 * XDL;
-    T yv[16];  // yv[m] = dinv[m] * x[m]
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      T sacc = 0;
-#pragma unroll
-      for (int m = 0; m < i; m++) sacc += a[(o + i) * LDA2 + o + m] * yv[m];
-      const T xv = (i < c) ? 0.0 : (i == c ? 1.0 : -sacc);
-      yv[i] = xv * dinv[o + i];
-      xj[i * XDL + c] = xv;
-    }
-  }
-  __syncthreads();
-  // full inverse: X(I,J) = -Linv16(I) * sum_{K=J}^{I-1} L(I,K) X(K,J); X(I,J)[i][j] kept at a[16J+j][16I+i].  A block
-  // column J of the inverse depends on L and on its own blocks only, so each wave owns whole columns -- {0}, {1,6},
-  // {2,5}, {3,4}: seven blocks each -- and walks down them with wave-local fences, no workgroup barrier.
-  for (int pass = 0; pass < 2; pass++) {
-    const int J = pass == 0 ? wv : 7 - wv;
-    if (pass == 1 && wv == 0) break;  // column 7 has no block below its diagonal
-    for (int I = J + 1; I < 8; I++) {
-      d4 acc = {0, 0, 0, 0};
-      for (int K = J; K < I; K++) {
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          const int k = 16 * K + 4 * kk + fk;
-          const T af = a[(16 * I + fr) * LDA2 + k] * dinv[k];
-          const T bf = (K == J) ? xd[(J * 16 + 4 * kk + fk) * XDL + fr] : a[(16 * J + fr) * LDA2 + k];
-          acc = RT<T>::mfma(af, bf, acc);
-        }
-      }
-      d4 out = {0, 0, 0, 0};
-#pragma unroll
-      for (int g = 0; g < 4; g++)
-        out = RT<T>::mfma(xd[(I * 16 + fr) * XDL + RT<T>::row(lane, g)], acc[g], out);
-#pragma unroll
-      for (int g = 0; g < 4; g++) a[(16 * J + fr) * LDA2 + 16 * I + RT<T>::row(lane, g)] = -out[g];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-  }
-  __syncthreads();
-  STAMP(4)
-  // LDS -> Linv tile (lower triangle only: the upper triangle of the buffer is zeroed once, when it is allocated) and D.
-  // The factored diagonal tile itself is not written back: nothing reads it (panel solves and sweeps use Linv and D).
-#pragma unroll 8
-  for (int it = 0; it < 32; it++) {
-    const int idx = 2 * (it * 256 + tid), i = idx >> 7, c0 = idx & (NB - 1);
-    if (c0 > i) continue;
-    d2 xv;
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-      const int c = c0 + e;
-      T x;
-      if (c < i)
-        x = ((i >> 4) == (c >> 4)) ? xd[((i >> 4) * 16 + (i & 15)) * XDL + (c & 15)] : a[c * LDA2 + i];
-      else
-        x = (c == i) ? (T)1 : (T)0;
-      xv[e] = x;
-    }
-    *reinterpret_cast<d2 *>(Linv_k + idx) = xv;
-  }
+  // last block row of the inverse: X(7,J) = -L16(7)^-1 acc(7,J)
+  for (int J = wv; J < 7; J += NW) inv_finalize(7, J);
   if (tid < NB) D_k[tid] = dd[tid];
-  STAMP(5)
+  STAMP(4)
   if (stamps && tid == 0)
     for (int q = 0; q < 6; q++) stamps[q] = tacc[q];
 #undef STAMP
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__restrict__ Linv_k,
+__global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(T *__restrict__ Skk, T *__restrict__ Linv_k,
                                                    T *__restrict__ D_k, int *__restrict__ flag,
                                                    unsigned long long *__restrict__ stamps,
                                                    const int *__restrict__ wait_ready) {
@@ -437,7 +474,7 @@ __global__ __launch_bounds__(256) void k_ldl_diag(T *__restrict__ Skk, T *__rest
   // hoisted launch: started early (while CUs were free), waits in place until the trailing update running beside it has
   // finished this tile
   if (wait_ready && !hoisted_wait(wait_ready, 1, flag)) return;
-  diag_tile<T>(Skk, Linv_k, D_k, flag, stamps, reinterpret_cast<T *>(smraw));
+  diag_tile<T, DIAG_THREADS / 64>(Skk, Linv_k, D_k, flag, stamps, reinterpret_cast<T *>(smraw));
 }
 
 // ---- 128 x 128 x (128 NP) tile product C = sum_p A_p * B_p' on the matrix cores ------------------------------------
@@ -1050,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_ldl_pairdiag(T *__restrict__ S, const i
   if (wait_ready && !hoisted_wait(wait_ready, need, flag)) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   T *Skk = S + tix(co, k, k) * NB * NB, *Lk = Linv + (int64_t)k * NB * NB, *Dk = D + (int64_t)k * NB;
-  diag_tile<T>(Skk, Lk, Dk, flag, nullptr, sm);
+  diag_tile<T, 4>(Skk, Lk, Dk, flag, nullptr, sm);
   __threadfence();  // this workgroup re-reads what it has just written (Linv_k now, L_{k+1,k} and V0_{k+1} below) from memory
   __syncthreads();
   T *ysh = sm + 2 * NB * LDK;  // behind the product's staging area
@@ -1117,7 +1154,7 @@ __global__ __launch_bounds__(256) void k_ldl_pairdiag(T *__restrict__ S, const i
   __threadfence();
   __syncthreads();
   T *Lk1 = Lk + NB * NB, *Dk1 = Dk + NB;
-  diag_tile<T>(S11, Lk1, Dk1, flag, nullptr, sm);
+  diag_tile<T, 4>(S11, Lk1, Dk1, flag, nullptr, sm);
   if (FWD) {  // y_{k+1} = Linv_{k+1} b_{k+1}
     __threadfence();
     __syncthreads();
@@ -1564,7 +1601,7 @@ void dense_ldl_free(DenseLDLT<T> *w) {
 template <typename T>
 static int launch_diag(ba_problem *p, DenseLDLT<T> *w, int k, hipStream_t st, const int *wait_ready = nullptr) {
   ProfScope ps(p, PC_LDL_DIAG, st);
-  hipLaunchKernelGGL(k_ldl_diag<T>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(T), st, w->S + tix(w->hco(), k, k) * NB * NB,
+  hipLaunchKernelGGL(k_ldl_diag<T>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_ELEMS * sizeof(T), st, w->S + tix(w->hco(), k, k) * NB * NB,
                      w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag, (unsigned long long *)nullptr,
                      wait_ready);
   return BA_OK;

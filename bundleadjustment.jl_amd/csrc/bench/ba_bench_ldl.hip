@@ -186,7 +186,8 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
   BA_HIP_CHECK(hipMemset(Li, 0, NB * NB * sizeof(double)));
   BA_HIP_CHECK(hipMalloc((void **)&D, NB * sizeof(double)));
   BA_HIP_CHECK(hipMalloc((void **)&flag, sizeof(int)));
-  BA_HIP_CHECK(hipMalloc((void **)&st, 6 * sizeof(unsigned long long)));
+  BA_HIP_CHECK(hipMalloc((void **)&st, 62 * sizeof(unsigned long long)));
+  BA_HIP_CHECK(hipMemset(st, 0, 62 * sizeof(unsigned long long)));
   std::vector<double> h((size_t)NB * NB, 0.0);
   for (int i = 0; i < NB; i++)
     for (int j = 0; j <= i; j++) h[(size_t)i * NB + j] = (i == j) ? 300.0 + i : 1.0 / (1 + i + j);
@@ -197,7 +198,7 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
   for (int rep = 0; rep < 3; rep++) {
     BA_HIP_CHECK(hipMemcpy(S, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
     BA_HIP_CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(double), 0, S, Li, D, flag, rep == 2 ? st : nullptr, (const int *)nullptr);
+    hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_ELEMS * sizeof(double), 0, S, Li, D, flag, rep == 2 ? st : nullptr, (const int *)nullptr);
     BA_HIP_CHECK(hipEventRecord(e1, 0));
     BA_HIP_CHECK(hipEventSynchronize(e1));
     if (rep == 1) BA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -215,9 +216,9 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
     mix(dv);
     fprintf(stderr, "[diag] output fingerprint %016llx  D[0] %.17g D[127] %.17g Linv[127][0] %.17g\n", hsh, dv[0], dv[127], li[(size_t)127 * NB]);
   }
-  unsigned long long hs[6];
+  unsigned long long hs[62];
   BA_HIP_CHECK(hipMemcpy(hs, st, sizeof hs, hipMemcpyDeviceToHost));
-  for (int q = 0; q < 6; q++) cycles6[q] = (double)hs[q];
+  for (int q = 0; q < 62; q++) cycles6[q] = (double)hs[q];  // 6 phases, then the busy time of wave w in stage s at [6 + 8 s + w]
   *ms_out = ms;
   (void)hipFree(S); (void)hipFree(Li); (void)hipFree(D); (void)hipFree(flag); (void)hipFree(st);
   return BA_OK;
@@ -458,7 +459,7 @@ extern "C" int ba_debug_diag_busy(int n, int fill_blocks, int fill_iters, double
       hipLaunchKernelGGL(k_mfma_probe<0>, dim3(fill_blocks), dim3(256), 0, sb, out, fill_iters);
     BA_HIP_CHECK(hipEventRecord(ev[0], sa));
     for (int q = 0; q < n; q++) {  // (the kernel only reads S: every launch factors the same tile)
-      hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(256), DIAG_LDS_ELEMS * sizeof(double), sa, S, Li, D, flag,
+      hipLaunchKernelGGL(k_ldl_diag<double>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_ELEMS * sizeof(double), sa, S, Li, D, flag,
                          (unsigned long long *)nullptr, (const int *)nullptr);
       BA_HIP_CHECK(hipEventRecord(ev[(size_t)q + 1], sa));
     }

@@ -10,7 +10,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 
 def load():
-    path = os.path.join(ROOT, "tools", "libba_bench.so")
+    path = os.path.join(ROOT, "tools", os.environ.get("BA_BENCH_LIB", "libba_bench.so"))
     if not os.path.exists(path):
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "bundleadjustment.jl_amd", "csrc"), "bench"])
     ba = ge.load_package()
