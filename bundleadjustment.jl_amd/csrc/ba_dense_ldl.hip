@@ -149,7 +149,8 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
   const int fr = lane & 15, fk = lane >> 4;
   // tile -> LDS: 16-byte loads, 16 in flight per thread (unpredicated: loads under a per-thread condition serialise).
   // The strict upper triangle of the LDS image is never read before the inverse phase writes it.
-  constexpr int NT = 64 * NW, LQ = NB * NB / 2 / NT / 2;  // threads; 16-byte loads per thread and round
+  constexpr int NT = 64 * NW, LQ = NB * NB / 2 / NT / 2;  // threads; 16-byte loads per thread and round (one round of
+                                                          // twice as many: no faster, 7.1 vs 6.5 kcycles)
 #pragma unroll
   for (int b0 = 0; b0 < 2; b0++) {
     d2 v[LQ];
@@ -346,7 +347,7 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
   // which the factorisation never touches), same lane, same register, and receives its terms in the order K = J, J+1,
   // ...: the sums are those of the former phase, bit for bit.  Every finished block goes to the Linv tile in global memory
   // at once: no store phase is left either.  The kernel k_ldl_diag runs this with eight waves (seven workers, two waves
-  // per SIMD so that one's LDS round trips hide behind the other's matrix instructions): 47.5 -> 37.3 us (tools/bench_diag.py).
+  // per SIMD so that one's LDS round trips hide behind the other's matrix instructions).
   auto inv16 = [&](int jb) {  // lanes 0..15 of one wave, one column each: l[i][m] = a[i][m] * dinv[m]
     const int o = 16 * jb, c = lane;
     T *xj = xd + jb * 16 * XDL;
@@ -422,39 +423,105 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
   if (!(BA_DIAG_EXP & 1) && wv == 3 && lane < 16) inv16(0);
   __syncthreads();
   STAMP(2)
-  for (int jb = 0; jb < 7; jb++) {
-    for (int t = wv; t < 7; t += NW) {  // seven tasks: block column jb + 1 of the factorisation, block row jb of the inverse
-      if (t < 7 - jb) block_update(jb, jb + 1 + t, jb + 1);
-      else if (!(BA_DIAG_EXP & 2)) inv_finalize(jb, t - (7 - jb));
-    }
-    __syncthreads();
-    STAMP(3)
-    unsigned long long c0 = 0;
-    if (stamps) c0 = __builtin_amdgcn_s_memtime();
-    if (wv == 0) {
-      if (!(BA_DIAG_EXP & 8)) do_pivots(jb + 1);
-    } else {
-      // trailing blocks (I, J), jb + 2 <= J <= I < 8, of the factorisation, then the inverse's (I, J), I > jb >= J
-      const int mb = 6 - jb, nblk = mb * (mb + 1) / 2, ninv = (BA_DIAG_EXP & 2) ? 0 : (7 - jb) * (jb + 1);
-      for (int t = wv - 1; t < nblk + ninv; t += NWK) {
-        if (t < nblk) {
-          int ii = 0;
-          while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-          const int jj = t - ii * (ii + 1) / 2;
-          block_update(jb, jb + 2 + ii, jb + 2 + jj);
-        } else {
-          const int e = t - nblk, J = e / (7 - jb), I = jb + 1 + e % (7 - jb);
-          inv_update(I, J, jb);
+  if constexpr (NW == 8) {
+    // Eight waves: two phases per block column, P(s) in the shadow of wave 0's chain (update of diagonal block s+1, then its
+    // factorisation) and A(s+1) in the shadow of the row solves -- the update of block column s+1 no longer has a phase
+    // and a barrier of its own.  Tasks (four matrix instructions each): F(I,J,s) trailing update of the factorisation with
+    // block column s; X(s,J) = -L16(s)^-1 acc(s,J); U(I,J,K) acc(I,J) += L(I,K) X(K,J).
+    //   P(s), seven workers:  X(s,J), J < s;  F(I,s+1,s), I > s+1 (the row solves of A(s+1) need them);
+    //                         U(I,J,s-1), I > s, J < s;  F(I,J,s), J > s+1, as far as three rounds of tasks go;
+    //   A(s+1), the five waves beside row solves and inv16:  U(s+1,J,s), J <= s (X(s+1,.) is due in P(s+1));  the rest of F.
+    // Every block still receives its terms in the order K = 0, 1, ...: same bits as the four-wave form below.
+    constexpr int CAP = 3 * NWK - 1;  // the wave that shares wave 0's SIMD sits out the third round (it was the last to
+                                      // arrive by ~700 cycles per stage)
+    // workers: the wave that shares wave 0's SIMD comes last; helpers of A: the two waves of the free SIMD first, the
+    // one that shares inv16's SIMD last
+    const int u = (wv == 4) ? 6 : (wv < 4 ? wv - 1 : wv - 2);
+    const int h = (wv == 2) ? 0 : (wv == 6) ? 1 : (wv == 4) ? 2 : (wv == 5) ? 3 : (wv == 7) ? 4 : -1;
+    auto f_task = [&](int s, int t) {  // t-th block of (I, J), s + 2 <= J <= I < 8
+      int ii = 0;
+      while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+      const int jj = t - ii * (ii + 1) / 2;
+      block_update(s, s + 2 + ii, s + 2 + jj);
+    };
+    for (int s = 0; s < 7; s++) {
+      const int nX = s, nC = 6 - s, nU = s * (7 - s), nF = (6 - s) * (7 - s) / 2;
+      const int nfix = nX + nC + nU, nP = nfix + nF < CAP ? nfix + nF : (nfix > CAP ? nfix : CAP);
+      unsigned long long c0 = 0;
+      if (stamps) c0 = __builtin_amdgcn_s_memtime();
+      if (wv == 0) {
+        block_update(s, s + 1, s + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        do_pivots(s + 1);
+      } else {
+        for (int r = 0; r < 3 + (nfix + NWK - 1) / NWK; r++) {
+          // rounds 0 and 1: seven tasks; from round 2 on: six
+          const int t = r < 2 ? NWK * r + u : 2 * NWK + (NWK - 1) * (r - 2) + u;
+          if ((r >= 2 && u == NWK - 1) || t >= nP) continue;
+          if (t < nX) {
+            inv_finalize(s, t);
+          } else if (t < nX + nC) {
+            block_update(s, s + 2 + (t - nX), s + 1);
+          } else if (t < nfix) {
+            const int e = t - nX - nC;
+            inv_update(s + 1 + e % (7 - s), e / (7 - s), s - 1);
+          } else {
+            f_task(s, t - nfix);
+          }
         }
       }
+      if (stamps && lane == 0) stamps[6 + s * 8 + wv] = __builtin_amdgcn_s_memtime() - c0;  // busy time of this wave
+      __syncthreads();
+      STAMP(1)
+      row_solves(s + 1);
+      if (wv == 3 && lane < 16) inv16(s + 1);
+      if (h >= 0) {
+        const int nA = (s + 1) + (nfix + nF - nP);
+        for (int t = h; t < nA; t += 5) {
+          if (t <= s) inv_update(s + 1, t, s);
+          else f_task(s, nP - nfix + (t - (s + 1)));
+        }
+      }
+      __syncthreads();
+      STAMP(2)
     }
-    if (stamps && lane == 0) stamps[6 + jb * 8 + wv] = __builtin_amdgcn_s_memtime() - c0;  // busy time of this wave
-    __syncthreads();
-    STAMP(1)
-    row_solves(jb + 1);
-    if (!(BA_DIAG_EXP & 1) && wv == 3 && lane < 16) inv16(jb + 1);
-    __syncthreads();
-    STAMP(2)
+  } else {
+    for (int jb = 0; jb < 7; jb++) {
+      for (int t = wv; t < 7; t += NW) {  // seven tasks: block column jb + 1 of the factorisation, block row jb of the inverse
+        if (t < 7 - jb) block_update(jb, jb + 1 + t, jb + 1);
+        else if (!(BA_DIAG_EXP & 2)) inv_finalize(jb, t - (7 - jb));
+      }
+      __syncthreads();
+      STAMP(3)
+      unsigned long long c0 = 0;
+      if (stamps) c0 = __builtin_amdgcn_s_memtime();
+      if (wv == 0) {
+        if (!(BA_DIAG_EXP & 8)) do_pivots(jb + 1);
+      } else {
+        // trailing blocks (I, J), jb + 2 <= J <= I < 8, of the factorisation, then the inverse's (I, J), I > jb >= J
+        const int mb = 6 - jb, nblk = mb * (mb + 1) / 2, ninv = (BA_DIAG_EXP & 2) ? 0 : (7 - jb) * (jb + 1);
+        for (int t = wv - 1; t < nblk + ninv; t += NWK) {
+          if (t < nblk) {
+            int ii = 0;
+            while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+            const int jj = t - ii * (ii + 1) / 2;
+            block_update(jb, jb + 2 + ii, jb + 2 + jj);
+          } else {
+            const int e = t - nblk, J = e / (7 - jb), I = jb + 1 + e % (7 - jb);
+            inv_update(I, J, jb);
+          }
+        }
+      }
+      if (stamps && lane == 0) stamps[6 + jb * 8 + wv] = __builtin_amdgcn_s_memtime() - c0;  // busy time of this wave
+      __syncthreads();
+      STAMP(1)
+      row_solves(jb + 1);
+      if (!(BA_DIAG_EXP & 1) && wv == 3 && lane < 16) inv16(jb + 1);
+      __syncthreads();
+      STAMP(2)
+    }
   }
   // last block row of the inverse: X(7,J) = -L16(7)^-1 acc(7,J)
   for (int J = wv; J < 7; J += NW) inv_finalize(7, J);
@@ -1393,17 +1460,19 @@ __global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const
     for (int r = half * 64; r < half * 64 + 64; r++) s += M[r * NB + c] * v[r];
     part[half][c] = s;
   };
+  // the tile indices first (compressed block-sparse storage: a tile outside the pattern does not exist): their table
+  // look-ups are dependent global loads, which left where they are used put three memory round trips on the chain of a
+  // launch that has nothing to hide them behind (19 -> 32 us per launch on Venice when the tables came in)
+  const int j = blockIdx.x == 0 ? 0 : (cols ? cols[blockIdx.x - 1] : blockIdx.x - 1);  // 0 .. k-2
+  const int64_t tkk = tix(co, k, k - 1), tkj = tix(co, k, j), tk1j = tix(co, k - 1, j);
   if (tid < NB) zk[tid] = y[(int64_t)k * NB + tid] / D[(int64_t)k * NB + tid];
   __syncthreads();
   matvec_t(Linv + (int64_t)k * NB * NB, zk);
   __syncthreads();
   if (tid < NB) xk[tid] = part[0][tid] + part[1][tid];
   __syncthreads();
-  {
-    const int64_t tkk = tix(co, k, k - 1);  // (compressed block-sparse storage: a tile outside the pattern does not exist)
-    if (tkk >= 0) matvec_t(S + tkk * NB * NB, xk);  // L_{k,k-1}' x_k
-    else part[half][c] = 0;
-  }
+  if (tkk >= 0) matvec_t(S + tkk * NB * NB, xk);  // L_{k,k-1}' x_k
+  else part[half][c] = 0;
   __syncthreads();
   if (tid < NB) {
     const T d = D[(int64_t)(k - 1) * NB + tid];
@@ -1422,8 +1491,6 @@ __global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const
     return;
   }
   // cols (block-sparse S): the tile columns in the pattern of row k or row k-1 (a tile outside the pattern holds zeros)
-  const int j = cols ? cols[blockIdx.x - 1] : blockIdx.x - 1;  // 0 .. k-2
-  const int64_t tkj = tix(co, k, j), tk1j = tix(co, k - 1, j);
   const T *Lkj = S + tkj * NB * NB, *Lk1j = S + tk1j * NB * NB;
   T s = 0;
   if (tkj >= 0 && tk1j >= 0) {
