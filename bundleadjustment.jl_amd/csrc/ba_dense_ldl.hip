@@ -70,7 +70,10 @@ constexpr size_t GEMM_LDS_ELEMS = (size_t)(DBUF ? 2 : 1) * 2 * NB * LDK;
 constexpr int LDA2 = 130;  // row stride 260 dwords = 4 mod 64: conflict-free MFMA operand reads
 constexpr int XDL = 18;
 constexpr int L16S = 18;   // row stride of the 16x16 multiplier block: 16-byte aligned rows for the row solves' paired reads
-constexpr int DIAG_THREADS = 512;  // k_ldl_diag: eight waves, two per SIMD (see diag_tile)
+#ifndef BA_DIAG_THREADS
+#define BA_DIAG_THREADS 512
+#endif
+constexpr int DIAG_THREADS = BA_DIAG_THREADS;  // k_ldl_diag: eight waves, two per SIMD (see diag_tile)
 constexpr size_t DIAG_LDS_ELEMS = (size_t)(NB * LDA2 + 8 * 16 * XDL + 2 * NB + 16 * L16S);
 
 // broadcast lane `src` (a compile-time constant after unrolling) of v to the whole wave: v_readlane_b32 into SGPRs

@@ -535,8 +535,7 @@ static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too
 }
 
 static int fetch_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st) {
-  BA_HIP_CHECK(hipMemcpyAsync(w->s.h_sh, w->scal, SH_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
-  BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+  BA_CHECK(launch_publish(w->scal, SH_COUNT, w->s.h_sh, w->s.scal_rep, RP_COUNT, w->s.h_rp, nullptr, nullptr, st));
   BA_HIP_CHECK(hipStreamSynchronize(st));
   return BA_OK;
 }
@@ -823,13 +822,12 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
   hipGraphExec_t &g = w->g_step[w->parity];
   if (!g) {
     const int grc = record_graph(st, &g, [&]() -> int {
-      BA_HIP_CHECK(hipMemcpyAsync(w->d_lambda, w->h_lambda, sizeof(double), hipMemcpyHostToDevice, st));
+      BA_CHECK(launch_fetch_scalar(w->h_lambda, w->d_lambda, st));
       BA_CHECK(linear_step(p, w, 1.0, normalize, st, facto_f32, w->d_lambda));
       BA_CHECK(step_scalars(p, w, st));
       BA_CHECK(trial_point(p, w, st, xf32));
-      BA_HIP_CHECK(hipMemcpyAsync(w->s.h_sh, w->scal, SH_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
-      BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
-      BA_HIP_CHECK(hipMemcpyAsync(w->h_flag, facto_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      BA_CHECK(launch_publish(w->scal, SH_COUNT, w->s.h_sh, w->s.scal_rep, RP_COUNT, w->s.h_rp, facto_f32 ? w->ldl32.flag : w->ldl.flag,
+                              w->h_flag, st));
       return BA_OK;
     });
     if (grc != BA_OK) {  // recording is an optimisation: without it the same launches are issued one by one
@@ -856,8 +854,7 @@ static int accept_refresh(ba_problem *p, LMWorkFull *w, bool xf32, hipStream_t s
   if (!g) {
     const int grc = record_graph(st, &g, [&]() -> int {
       BA_CHECK(refresh_linearisation(p, w, false, st, xf32));
-      BA_HIP_CHECK(hipMemcpyAsync(w->s.h_sh, w->scal, SH_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
-      BA_HIP_CHECK(hipMemcpyAsync(w->s.h_rp, w->s.scal_rep, RP_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+      BA_CHECK(launch_publish(w->scal, SH_COUNT, w->s.h_sh, w->s.scal_rep, RP_COUNT, w->s.h_rp, nullptr, nullptr, st));
       return BA_OK;
     });
     if (grc != BA_OK) {
@@ -868,6 +865,27 @@ static int accept_refresh(ba_problem *p, LMWorkFull *w, bool xf32, hipStream_t s
     }
   }
   BA_HIP_CHECK(hipGraphLaunch(g, st));
+  BA_HIP_CHECK(hipStreamSynchronize(st));
+  return BA_OK;
+}
+
+// Recorded sequences only: the refresh after an accepted step and the NEXT trial step (its damping is known at the moment
+// of acceptance) are submitted back to back and waited for once.  The host's work between two launches -- waking up from
+// the wait, the accept test, submitting a sequence of ~110 nodes -- otherwise leaves the device idle twice per iteration
+// (Dubrovnik: 31 + 79 us of a 3.0 ms iteration, LadyBug: the same of 0.44 ms; rocprofv3 kernel trace).  The refresh and the
+// trial write disjoint scalar slots, so one read of the pinned buffers serves both.  If the stopping tests that need the
+// refreshed |J'r| or |x| then end the loop, the prefetched step is dropped (never counted, x untouched).
+static bool can_prefetch_trial(ba_problem *p, LMWorkFull *w, int normalize, bool facto_f32, bool xf32) {
+  const char *e = getenv("BA_LM_PREFETCH");  // read per call: a test compares both forms in one process
+  if ((e && e[0] == '0') || !graphs_allowed(p, w)) return false;
+  const int key = normalize + 4 * (facto_f32 ? 1 : 0) + 8 * (xf32 ? 1 : 0);
+  return w->g_key == key && w->g_step[w->parity] && w->g_refresh[w->parity];
+}
+static int accept_refresh_and_trial(LMWorkFull *w, double lambda, bool facto_f32, hipStream_t st) {
+  BA_HIP_CHECK(hipGraphLaunch(w->g_refresh[w->parity], st));
+  *w->h_lambda = lambda;  // read by the trial sequence's first kernel; the previous trial sequence has completed
+  w->last_f32 = facto_f32;
+  BA_HIP_CHECK(hipGraphLaunch(w->g_step[w->parity], st));
   BA_HIP_CHECK(hipStreamSynchronize(st));
   return BA_OK;
 }
@@ -1092,14 +1110,15 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   bool small_obj_change = false, fail2 = false;
   int iter = 0;
   bool tired = iter > ite_max;
-  bool accepted = false;
+  bool accepted = false, have_trial = false;
   int rc = BA_OK;
   const double t_loop = wall();
 
   while (!(small_step || first_order || small_residual || small_obj_change || tired || fail2)) {
     if (V) iter++;                                                                           // lm.jl:127
     if (!V && cb) cb(cb_ctx, iter, obj.v, ts::sub(old_obj, obj).v, norm_Jtr.v, lambda.v, norm_delta.v, dr2.v, accepted);  // LevenbergMarquardt.jl:143-147
-    if ((rc = trial_step(p, w, lambda.v, o->normalize, facto_f32, xf32, st)) != BA_OK) break;  // lm.jl:154-254
+    if (have_trial) have_trial = false;  // submitted with the refresh of the step accepted last (accept_refresh_and_trial)
+    else if ((rc = trial_step(p, w, lambda.v, o->normalize, facto_f32, xf32, st)) != BA_OK) break;  // lm.jl:154-254
     stats->n_factor++;
     stats->n_residual++;
     if (*w->h_flag == 2) {
@@ -1189,7 +1208,12 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
       old_obj = obj;
       norm_r = norm_rsuiv;
       obj = obj_suiv;
-      if ((rc = accept_refresh(p, w, xf32, st)) != BA_OK) break;  // J, J'r  (lm.jl:341,370)
+      // (what of the stopping tests is known before the refresh decides whether the next trial step goes out with it)
+      const bool stop_known = norm_r.v < restol.v || ts::sub(old_obj, obj).v < ts::add(oatol, ts::mul(ortol, old_obj)).v || iter > ite_max;
+      if (!stop_known && can_prefetch_trial(p, w, o->normalize, facto_f32, xf32)) {
+        if ((rc = accept_refresh_and_trial(w, lambda.v, facto_f32, st)) != BA_OK) break;
+        have_trial = true;
+      } else if ((rc = accept_refresh(p, w, xf32, st)) != BA_OK) break;  // J, J'r  (lm.jl:341,370)
       stats->n_jacobian++;
       norm_Jtr = norm_of(h_sh[SH_GP] + h_rp[RP_GC], W);
       norm_x = norm_of(h_sh[SH_X_P] + h_rp[RP_X_C], W);

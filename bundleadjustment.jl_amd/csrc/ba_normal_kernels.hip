@@ -1411,6 +1411,34 @@ int launch_sumsq_multi(ba_problem *p, SumsqJobs *jobs, double *d_partial_multi, 
   return BA_OK;
 }
 
+// The LM controller's scalars to pinned host memory and the damping from it, by kernels that address the host buffers
+// directly (hipHostMalloc memory is mapped): in a recorded launch sequence each of the former three + one copy nodes cost a
+// dispatch of ~5 us of its own.
+__global__ void k_publish(const double *__restrict__ a, int na, double *__restrict__ ha, const double *__restrict__ b, int nb,
+                          double *__restrict__ hb, const int *__restrict__ flag, int *__restrict__ hflag) {
+  const int t = threadIdx.x;
+  if (t < na) ha[t] = a[t];
+  if (t < nb) hb[t] = b[t];
+  if (t == 0 && flag) hflag[0] = flag[0];
+}
+__global__ void k_fetch_scalar(const double *__restrict__ h, double *__restrict__ d) { d[0] = h[0]; }
+
+int launch_publish(const double *d_a, int na, double *h_a, const double *d_b, int nb, double *h_b, const int *d_flag, int *h_flag,
+                   hipStream_t st) {
+  if (na > 64 || nb > 64) {
+    ba_set_error("launch_publish: more than 64 scalars");
+    return BA_ERR_ARG;
+  }
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, d_a, na, h_a, d_b, nb, h_b, d_flag, h_flag);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+int launch_fetch_scalar(const double *h, double *d, hipStream_t st) {
+  hipLaunchKernelGGL(k_fetch_scalar, dim3(1), dim3(1), 0, st, h, d);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
 int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st) {
   if (n == 0) return BA_OK;
   hipLaunchKernelGGL(k_axpy, dim3(grid_for(n, BLK)), dim3(BLK), 0, st, n, d_x, d_d, d_y);
