@@ -539,8 +539,11 @@ template <typename T>
 __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(T *__restrict__ Skk, T *__restrict__ Linv_k,
                                                    T *__restrict__ D_k, int *__restrict__ flag,
                                                    unsigned long long *__restrict__ stamps,
-                                                   const int *__restrict__ wait_ready) {
+                                                   const int *__restrict__ wait_ready, int clear_flag = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  // first kernel of an in-order factorisation: the pivot flag is cleared here instead of by a memset node of its own (the
+  // first pivot is behind the tile's load and a barrier)
+  if (clear_flag && threadIdx.x == 0) *flag = 0;
   // hoisted launch: started early (while CUs were free), waits in place until the trailing update running beside it has
   // finished this tile
   if (wait_ready && !hoisted_wait(wait_ready, 1, flag)) return;
@@ -1292,10 +1295,22 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
   }
   T *Sij = S + tix(co, i, j) * NB * NB;
   typename RT<T>::v4 acc[4][4];
+  if constexpr ((DBG & 64) != 0) {
+    // probe: the accumulators start as -C (loads in flight beside the first operand chunk), the epilogue stores -acc
+    const int lane0 = threadIdx.x & 63, wv0 = threadIdx.x >> 6;
+    const T *c0 = Sij + ((wv0 >> 1) * 64) * NB + (wv0 & 1) * 64 + (lane0 & 15);
 #pragma unroll
-  for (int m = 0; m < 4; m++)
+    for (int m = 0; m < 4; m++)
 #pragma unroll
-    for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
+      for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[m][n][g] = -c0[(16 * m + RT<T>::row(lane0, g)) * NB + 16 * n];
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  }
   const int io = (DBG & 2) ? base : i, jo = (DBG & 2) ? base : j;
   if constexpr ((DBG & 16) != 0 && sizeof(T) == 8)
     tile_gemm_abt_dma(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
@@ -1318,6 +1333,14 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
   // epilogue: the 64 values of a lane are read-modify-written in two batches of 32 so that 32 loads are in flight at once
   T *cbase = Sij + wr * NB + wc + (lane & 15);
+  if constexpr ((DBG & 64) != 0) {
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * n] = -acc[m][n][g];
+  } else
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     T cv[2][4][4];
@@ -1669,11 +1692,11 @@ void dense_ldl_free(DenseLDLT<T> *w) {
 }
 
 template <typename T>
-static int launch_diag(ba_problem *p, DenseLDLT<T> *w, int k, hipStream_t st, const int *wait_ready = nullptr) {
+static int launch_diag(ba_problem *p, DenseLDLT<T> *w, int k, hipStream_t st, const int *wait_ready = nullptr, bool clear_flag = false) {
   ProfScope ps(p, PC_LDL_DIAG, st);
   hipLaunchKernelGGL(k_ldl_diag<T>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_ELEMS * sizeof(T), st, w->S + tix(w->hco(), k, k) * NB * NB,
                      w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, w->flag, (unsigned long long *)nullptr,
-                     wait_ready);
+                     wait_ready, clear_flag ? 1 : 0);
   return BA_OK;
 }
 
@@ -1790,7 +1813,6 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
   const int nt = (int)w->nt;
   const int64_t panel = (int64_t)nt * NB * NB;
   T *Vs[2][2] = {{w->V, w->V + panel}, {w->V + 2 * panel, w->V + 3 * panel}};
-  BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
   constexpr int HOIST_MIN_TILES = 32;  // below ~2 rounds of tiles the update is shorter than wait + factor
   // The waiting workgroup keeps one CU of one XCD from the update, whose blocks the hardware deals round-robin to the
   // XCDs: that XCD runs 32/31 longer and the launch ends with it -- 3 % of the update time, which grows as nt^3 while
@@ -1799,7 +1821,10 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
   constexpr int HOIST_MAX_TILES = 224;
   static const bool hoist_off = [] { const char *e = getenv("BA_LDL_HOIST"); return e && e[0] == '0'; }();
   w->hoisting = !p->prof_on && !hoist_off && !w->hoist_disabled && !p->comm.active() && nt >= HOIST_MIN_TILES + 2 && nt <= HOIST_MAX_TILES;
+  // the pivot flag: hoisted kernels read it (an earlier tile gave up) before tile 0 is factored -- cleared ahead of the
+  // fork; in order, the first diagonal kernel clears it
   if (w->hoisting) {
+    BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
     BA_HIP_CHECK(hipMemsetAsync(w->ready, 0, (size_t)nt * sizeof(int), st));
     // one fork for the whole factorisation: the hoisted kernels only depend on their flags (and on stream order among
     // themselves); each gets its CU in the idle gaps of the panel chain before the trailing update it waits for starts
@@ -1814,7 +1839,7 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
   static const int fuse_min = [] { const char *e = getenv("BA_LDL_FUSE_MIN"); return e ? atoi(e) : 48; }();
   static const bool fuse_off = [] { const char *e = getenv("BA_LDL_FUSE"); return e && e[0] == '0'; }();
   auto fused = [&](int k) { return w->hoisting && !fuse_off && k >= 2 && k + 1 < nt && nt - k >= fuse_min; };
-  launch_diag(p, w, 0, st);
+  launch_diag(p, w, 0, st, nullptr, !w->hoisting);
   for (int k = 0, q = 0; k < nt; k += 2, q ^= 1) {
     T *V0 = Vs[q][0], *V1 = Vs[q][1];
     const bool more = k + 2 < nt;
@@ -1977,14 +2002,13 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
   const TilePattern *pat = w->pat;
   T *V0 = w->V, *V1 = w->V + (int64_t)nt * NB * NB;
   T *y = w->D + w->nt * NB;
-  BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));
   w->hoisting = false;
   for (int k = 0, q = 0; k < nt; k += 2, q++) {
     const int l0 = pat->prow_ptr[(size_t)q], l1 = pat->prow_ptr[(size_t)q + 1];
     const int c1 = l1 - l0;                      // {k+1} + U_q
     const int c2 = c1 > 0 ? c1 - 1 : 0;          // U_q
     const int *rows1 = w->prow + l0, *rows2 = w->prow + l0 + 1;
-    launch_diag(p, w, k, st);
+    launch_diag(p, w, k, st, nullptr, k == 0);  // (the first one clears the pivot flag)
     if (c1 == 0) {  // last, single tile column: y_k only
       if (d_b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k, (const int *)nullptr);
       break;

@@ -315,7 +315,7 @@ static int lm_ensure(ba_problem *p) {
   BA_CHECK(dmalloc(&w->Hcc, 45 * ncams));
   BA_CHECK(dmalloc(&w->colscale, 9 * ncams));
   BA_CHECK(dmalloc(&w->partial, std::max<int64_t>(RED_BLOCKS, (npnts + 255) / 256)));  // k_wtv<true>: one partial per 256 points
-  BA_CHECK(dmalloc(&w->partial_multi, (int64_t)4 * RED_BLOCKS));
+  BA_CHECK(dmalloc(&w->partial_multi, (int64_t)SUMSQ_JOBS * RED_BLOCKS));
   BA_HIP_CHECK(hipMalloc((void **)&w->cam_pnt, (size_t)(p->nobs > 0 ? p->nobs : 1) * sizeof(int)));
   BA_CHECK(launch_cam_pnt(p, w->cam_pnt, p->stream));
   BA_CHECK(dmalloc(&w->s.scal_rep, (int64_t)RP_COUNT));
@@ -495,7 +495,8 @@ static int reduce_camera_system(ba_problem *p, LMWorkFull *w, hipStream_t st, bo
 }
 
 // r, J and the normal-equation blocks at w->x; fills sharded/replicated scalars RSQ?, GP, GC, X_P, X_C
-static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too, hipStream_t st, bool xf32 = false) {
+// publish: the last reduction kernel also writes the controller's scalars to the pinned host buffers (recorded sequences)
+static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too, hipStream_t st, bool xf32 = false, bool publish = false) {
   if (xf32) {  // w->x holds Float32 values: evaluate with the Float32 kernels, widen (exact)
     BA_CHECK(launch_convert(w->x, w->xf, w->nvar, st));
     if (residual_too) {
@@ -513,24 +514,25 @@ static int refresh_linearisation(ba_problem *p, LMWorkFull *w, bool residual_too
   }
   BA_CHECK(launch_point_blocks(p, w->J, w->r, w->Hpp, w->gp, st));
   BA_CHECK(launch_cam_blocks(p, w->J, w->r, w->Hcc, w->gc, st));
-  {  // |r|^2, |gp|^2, |x_points|^2 in one launch pair (bit-identical to three launch_sumsq calls)
-    SumsqJobs jobs;
-    jobs.add(w->r, w->nequ, w->scal, SH_RSQ);
-    jobs.add(w->gp, 3 * p->npnts, w->scal, SH_GP);
-    jobs.add(w->x, 3 * p->npnts, w->scal, SH_X_P);
-    BA_CHECK(launch_sumsq_multi(p, &jobs, w->partial_multi, st));
-  }
   // gc, the diagonal of the camera block (the column scalings need the global one) and the linearisation scalars are
   // adjacent in the reduce buffer: one all-reduce
   BA_CHECK(launch_hcc_diag(p, w->Hcc, w->hdiag, st));
-  BA_CHECK(comm_sum(p, w, w->s.off_gc, 2 * w->npad + SH_LIN_COUNT, st));
-  if (w->f16) BA_CHECK(launch_col_sq(p, w->Hpp, w->hdiag, w->jn2, st));  // |J_j|^2 before the blocks are overwritten by scaled ones
-  {
-    SumsqJobs jobs;
-    jobs.add(w->gc, w->n, w->s.scal_rep, RP_GC);
-    jobs.add(w->x + 3 * p->npnts, w->n, w->s.scal_rep, RP_X_C);
+  // |r|^2, |gp|^2, |x_points|^2 and -- of the all-reduced gc -- |gc|^2, |x_cameras|^2: one launch pair on one rank, two with a
+  // communicator (the camera sums wait for the all-reduce); bit-identical to launch_sumsq per vector either way
+  SumsqJobs jobs;
+  jobs.add(w->r, w->nequ, w->scal, SH_RSQ);
+  jobs.add(w->gp, 3 * p->npnts, w->scal, SH_GP);
+  jobs.add(w->x, 3 * p->npnts, w->scal, SH_X_P);
+  if (p->comm.active()) {
     BA_CHECK(launch_sumsq_multi(p, &jobs, w->partial_multi, st));
+    BA_CHECK(comm_sum(p, w, w->s.off_gc, 2 * w->npad + SH_LIN_COUNT, st));
+    jobs = SumsqJobs();
   }
+  if (w->f16) BA_CHECK(launch_col_sq(p, w->Hpp, w->hdiag, w->jn2, st));  // |J_j|^2 before the blocks are overwritten by scaled ones
+  jobs.add(w->gc, w->n, w->s.scal_rep, RP_GC);
+  jobs.add(w->x + 3 * p->npnts, w->n, w->s.scal_rep, RP_X_C);
+  if (publish) jobs.publish(w->scal, SH_COUNT, w->s.h_sh, w->s.scal_rep, RP_COUNT, w->s.h_rp, nullptr, nullptr);
+  BA_CHECK(launch_sumsq_multi(p, &jobs, w->partial_multi, st));
   return BA_OK;
 }
 
@@ -617,8 +619,9 @@ static int pcg_solve(ba_problem *p, LMWorkFull *w, double lambda, hipStream_t st
 }
 
 // delta = -(J'J + lambda I)^-1 J'r at the current linearisation; also |J delta + r|^2 -> SH_MODEL, |delta|^2
+// h_lambda (recorded sequences): pinned host scalar the first kernel copies into d_lambda
 static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize, hipStream_t st,
-                       bool facto_f32 = false, const double *d_lambda = nullptr) {
+                       bool facto_f32 = false, const double *d_lambda = nullptr, const double *h_lambda = nullptr) {
   // d_lambda: the damping is read from device memory (recorded launches); `lambda` is then the multiplier 1
   // every rank holds partial Hcc / Schur sums; the lambda I of the camera block is added by rank 0 only
   const double lam_diag = (p->rank == 0) ? lambda : 0.0;
@@ -635,7 +638,10 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
     damp = w->damp;
     normalize = 0;  // lm.jl:156,232: no column scaling of J in the Float16 branch
   }
-  BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, d_lambda, damp));
+  // (single-rank direct path: the right-hand side buffer is cleared by this kernel instead of a memset node of its own)
+  const bool rhs_here = !w->pcg && !w->ldl.own_only;
+  BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, h_lambda ? h_lambda : d_lambda, damp,
+                             h_lambda ? const_cast<double *>(d_lambda) : nullptr, rhs_here ? w->rhs : nullptr, rhs_here ? w->npad : 0));
   if (w->pcg) {  // the reduced camera system is applied, not formed (pcg_solve); no column scaling: block Jacobi has its own
     BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
     BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
@@ -672,7 +678,6 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   } else {
     BA_CHECK(launch_schur_blocks(p, &w->tasks, Jl, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
                                  p->rank == 0 ? w->npad : w->n, st, d_lambda, damp, w->ldl.s_tiles));
-    BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
     BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
     BA_CHECK(reduce_camera_system(p, w, st, reduce32));
   }
@@ -716,12 +721,13 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
 }
 
 // cr: the model value is |J delta + cr r|^2 (1 outside the line search)
-static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st, double cr = -1.0) {
+// defer_delta: |delta_points|^2 and |delta_cameras|^2 are left to trial_point (one reduction pair with |r_trial|^2)
+static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st, double cr = -1.0, bool defer_delta = false) {
   const bool first = cr < 0;  // the step as linear_step left it (the line search calls with a rescaled delta and its own cr)
   if (first) cr = w->cr0();
   if (!(first && w->model_done)) BA_CHECK(launch_model_sq(p, w->J_lin(), w->r_lin(), w->delta, w->partial, w->scal, SH_MODEL, st, cr));
   w->model_done = false;
-  {
+  if (!defer_delta) {
     SumsqJobs jobs;
     jobs.add(w->delta, 3 * p->npnts, w->scal, SH_DELTA_P);
     jobs.add(w->delta + 3 * p->npnts, w->n, w->s.scal_rep, RP_DELTA_C);
@@ -730,7 +736,10 @@ static int step_scalars(ba_problem *p, LMWorkFull *w, hipStream_t st, double cr 
   return BA_OK;
 }
 
-static int trial_point(ba_problem *p, LMWorkFull *w, hipStream_t st, bool xf32 = false) {
+// with_delta: the step's two norms ride with |r_trial|^2 (step_scalars was told to leave them); publish_flag: the reduction
+// also writes the controller's scalars and this pivot flag to the pinned host buffers (recorded sequences)
+static int trial_point(ba_problem *p, LMWorkFull *w, hipStream_t st, bool xf32 = false, bool with_delta = false,
+                       const int *publish_flag = nullptr) {
   BA_CHECK(launch_axpy(p, w->nvar, w->x, w->delta, w->x_trial, st));
   if (xf32) {  // x_suiv is a Float32 vector in the reference: round, evaluate in Float32
     BA_CHECK(launch_convert(w->x_trial, w->xf, w->nvar, st));
@@ -740,8 +749,13 @@ static int trial_point(ba_problem *p, LMWorkFull *w, hipStream_t st, bool xf32 =
   } else {
     BA_CHECK(launch_residual_f64(p, w->x_trial, w->r_trial, st));
   }
-  BA_CHECK(launch_sumsq(p, w->nequ, w->r_trial, w->partial, w->scal, SH_RSQ_TRIAL, st));
-  return BA_OK;
+  if (!with_delta) return launch_sumsq(p, w->nequ, w->r_trial, w->partial, w->scal, SH_RSQ_TRIAL, st);
+  SumsqJobs jobs;
+  jobs.add(w->delta, 3 * p->npnts, w->scal, SH_DELTA_P);
+  jobs.add(w->delta + 3 * p->npnts, w->n, w->s.scal_rep, RP_DELTA_C);
+  jobs.add(w->r_trial, w->nequ, w->scal, SH_RSQ_TRIAL);
+  if (publish_flag) jobs.publish(w->scal, SH_COUNT, w->s.h_sh, w->s.scal_rep, RP_COUNT, w->s.h_rp, publish_flag, w->h_flag);
+  return launch_sumsq_multi(p, &jobs, w->partial_multi, st);
 }
 
 static int check_pivot(ba_problem *p, LMWorkFull *w, hipStream_t st) {
@@ -801,8 +815,8 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
                       hipStream_t st) {
   if (!graphs_allowed(p, w)) {
     BA_CHECK(linear_step(p, w, lambda, normalize, st, facto_f32));
-    BA_CHECK(step_scalars(p, w, st));
-    BA_CHECK(trial_point(p, w, st, xf32));
+    BA_CHECK(step_scalars(p, w, st, -1.0, true));
+    BA_CHECK(trial_point(p, w, st, xf32, true));
     BA_CHECK(comm_sum(p, w, w->s.off_scal + SH_TRIAL_FIRST, SH_TRIAL_COUNT, st));
     BA_HIP_CHECK(hipMemcpyAsync(w->h_flag, w->last_f32 ? w->ldl32.flag : w->ldl.flag, sizeof(int), hipMemcpyDeviceToHost, st));
     BA_CHECK(fetch_scalars(p, w, st));  // (synchronises st)
@@ -822,12 +836,9 @@ static int trial_step(ba_problem *p, LMWorkFull *w, double lambda, int normalize
   hipGraphExec_t &g = w->g_step[w->parity];
   if (!g) {
     const int grc = record_graph(st, &g, [&]() -> int {
-      BA_CHECK(launch_fetch_scalar(w->h_lambda, w->d_lambda, st));
-      BA_CHECK(linear_step(p, w, 1.0, normalize, st, facto_f32, w->d_lambda));
-      BA_CHECK(step_scalars(p, w, st));
-      BA_CHECK(trial_point(p, w, st, xf32));
-      BA_CHECK(launch_publish(w->scal, SH_COUNT, w->s.h_sh, w->s.scal_rep, RP_COUNT, w->s.h_rp, facto_f32 ? w->ldl32.flag : w->ldl.flag,
-                              w->h_flag, st));
+      BA_CHECK(linear_step(p, w, 1.0, normalize, st, facto_f32, w->d_lambda, w->h_lambda));
+      BA_CHECK(step_scalars(p, w, st, -1.0, true));
+      BA_CHECK(trial_point(p, w, st, xf32, true, facto_f32 ? w->ldl32.flag : w->ldl.flag));  // (+ scalars and flag to the host)
       return BA_OK;
     });
     if (grc != BA_OK) {  // recording is an optimisation: without it the same launches are issued one by one
@@ -853,8 +864,7 @@ static int accept_refresh(ba_problem *p, LMWorkFull *w, bool xf32, hipStream_t s
   hipGraphExec_t &g = w->g_refresh[w->parity];
   if (!g) {
     const int grc = record_graph(st, &g, [&]() -> int {
-      BA_CHECK(refresh_linearisation(p, w, false, st, xf32));
-      BA_CHECK(launch_publish(w->scal, SH_COUNT, w->s.h_sh, w->s.scal_rep, RP_COUNT, w->s.h_rp, nullptr, nullptr, st));
+      BA_CHECK(refresh_linearisation(p, w, false, st, xf32, true));  // (+ scalars to the host)
       return BA_OK;
     });
     if (grc != BA_OK) {

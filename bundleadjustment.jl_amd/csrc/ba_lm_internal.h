@@ -35,20 +35,31 @@ struct SchurChunk {
   int64_t nkeys = 0, nskeys = 0;
 };
 
-// up to four sums of squares in one launch pair (launch_sumsq_multi): vector, length, destination array and slot
+// up to six sums of squares in one launch pair (launch_sumsq_multi): vector, length, destination array and slot; the
+// second kernel (one workgroup) can also publish the controller's scalars to pinned host memory once every sum is in place
+constexpr int SUMSQ_JOBS = 6;
 struct SumsqJobs {
   int count = 0;
-  const double *v[4] = {nullptr, nullptr, nullptr, nullptr};
-  int64_t n[4] = {0, 0, 0, 0};
-  double *out[4] = {nullptr, nullptr, nullptr, nullptr};
-  int slot[4] = {0, 0, 0, 0};
-  int nb[4] = {0, 0, 0, 0};  // filled by the launcher
+  const double *v[SUMSQ_JOBS] = {};
+  int64_t n[SUMSQ_JOBS] = {};
+  double *out[SUMSQ_JOBS] = {};
+  int slot[SUMSQ_JOBS] = {};
+  int nb[SUMSQ_JOBS] = {};  // filled by the launcher
+  // publish (optional; as launch_publish): a[0..na) -> ha, b[0..nb2) -> hb, flag[0] -> hflag
+  const double *pa = nullptr, *pb = nullptr;
+  double *ha = nullptr, *hb = nullptr;
+  const int *pflag = nullptr;
+  int *hflag = nullptr;
+  int na = 0, nb2 = 0;
   void add(const double *vec, int64_t len, double *dst, int s) {
     v[count] = vec;
     n[count] = len;
     out[count] = dst;
     slot[count] = s;
     count++;
+  }
+  void publish(const double *a, int na_, double *h_a, const double *b, int nb_, double *h_b, const int *flag, int *h_flag) {
+    pa = a; na = na_; ha = h_a; pb = b; nb2 = nb_; hb = h_b; pflag = flag; hflag = h_flag;
   }
 };
 
@@ -69,7 +80,7 @@ struct LMWork {
   // facto_type = Float16: |J_j|^2, column norms, damping vector (nvar each), quantised J (24/obs) and r; allocated on first use
   double *jn2 = nullptr, *dcol = nullptr, *damp = nullptr, *Jq = nullptr, *rq = nullptr;
   double *partial = nullptr;             // RED_BLOCKS
-  double *partial_multi = nullptr;       // 4 x RED_BLOCKS (launch_sumsq_multi)
+  double *partial_multi = nullptr;       // SUMSQ_JOBS x RED_BLOCKS (launch_sumsq_multi)
   int *cam_pnt = nullptr;                // nobs: the point of every observation in camera order (pnt0[cam_obs[q]])
   double *scal = nullptr;                // SC_COUNT device scalars
   double *h_scal = nullptr;              // pinned host mirror
@@ -79,7 +90,9 @@ struct LMWork {
 
 // d_lambda (optional device scalar): the damping used is lambda * d_lambda[0] (hipGraph replays, ba_lm.hip)
 int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const double *d_gp, double *d_Uinv,
-                      double *d_u, hipStream_t st, const double *d_lambda = nullptr, const double *d_damp = nullptr);
+                      double *d_u, hipStream_t st, const double *d_lambda = nullptr, const double *d_damp = nullptr,
+                      double *d_lambda_copy = nullptr /* d_lambda (may be pinned host memory) is copied here */,
+                      double *d_zero = nullptr, int64_t nzero = 0 /* cleared on the way */);
 int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, const double *d_Uinv, double *d_Y,
                         const double *d_Hcc, double lambda, double *d_S, const int64_t *d_col_off, int64_t n, int64_t npad,
                         hipStream_t st, const double *d_lambda = nullptr, const double *d_damp = nullptr, int64_t s_tiles = 0);
@@ -106,7 +119,7 @@ int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial,
 int launch_publish(const double *d_a, int na, double *h_a, const double *d_b, int nb, double *h_b, const int *d_flag, int *h_flag,
                    hipStream_t st);
 int launch_fetch_scalar(const double *h, double *d, hipStream_t st);
-int launch_sumsq_multi(ba_problem *p, SumsqJobs *jobs, double *d_partial_multi /* 4 RED_BLOCKS */, hipStream_t st);
+int launch_sumsq_multi(ba_problem *p, SumsqJobs *jobs, double *d_partial_multi /* SUMSQ_JOBS RED_BLOCKS */, hipStream_t st);
 int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st);
 int launch_hcc_diag(ba_problem *p, const double *d_Hcc, double *d_hdiag, hipStream_t st);
 int launch_cam_scale(ba_problem *p, const double *d_hdiag, double add, double *d_dsc, hipStream_t st,

@@ -318,8 +318,14 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ c
 __global__ __launch_bounds__(BLK) void k_schur_prep(int64_t npnts, double lambda, const double *__restrict__ lam_dev,
                                                      const double *__restrict__ Hpp, const double *__restrict__ gp,
                                                      double *__restrict__ Uinv, double *__restrict__ u,
-                                                     const double *__restrict__ damp) {
+                                                     const double *__restrict__ damp, double *__restrict__ lam_copy,
+                                                     double *__restrict__ zero, int64_t nzero) {
   int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  // first kernel of a step: two chores ride along that were launches of their own (recorded sequences pay ~5 us per
+  // node): the damping, read here from pinned host memory, is left in device memory for the kernels that follow, and the
+  // right-hand side of the camera system is cleared for the sums of k_schur_rhs
+  if (lam_copy && p == 0) lam_copy[0] = lam_dev[0];
+  for (int64_t i = p; i < nzero; i += (int64_t)gridDim.x * BLK) zero[i] = 0.0;
   if (p >= npnts) return;
   if (lam_dev) lambda *= lam_dev[0];
   const double *h = Hpp + 6 * p;
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(BLK) void k_sum_partials(int np, const double *__re
 // Several sums of squares in ONE launch pair (the LM loop needs |r|^2, |gp|^2, |x_p|^2 ... one after the other: on small
 // problems every one of those two-kernel launches costs more in launch latency than in work).  Vector v owns the blocks
 // [v RED_BLOCKS, v RED_BLOCKS + nb_v) and sums exactly what k_sumsq would with a grid of nb_v blocks; the second kernel is
-// k_sum_partials per vector: the results are bit-identical to the separate launches.
+// k_sum_partials per vector, one after the other in ONE workgroup: the results are bit-identical to the separate launches.
 __global__ __launch_bounds__(BLK) void k_sumsq_multi(SumsqJobs jobs, double *__restrict__ partial) {
   __shared__ double red[BLK / 64];
   const int v = blockIdx.x / RED_BLOCKS, b = blockIdx.x % RED_BLOCKS;
@@ -743,14 +749,23 @@ __global__ __launch_bounds__(BLK) void k_sumsq_multi(SumsqJobs jobs, double *__r
 }
 __global__ __launch_bounds__(BLK) void k_sum_partials_multi(SumsqJobs jobs, const double *__restrict__ partial) {
   __shared__ double red[BLK / 64];
-  const int v = blockIdx.x;
-  const double *pp = partial + v * RED_BLOCKS;
-  double acc = 0;
-  for (int i = threadIdx.x; i < jobs.nb[v]; i += BLK) acc += pp[i];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) jobs.out[v][jobs.slot[v]] = ((red[0] + red[1]) + red[2]) + red[3];
+  for (int v = 0; v < jobs.count; v++) {  // one workgroup: the jobs one after the other (at most 1024 partials each)
+    const double *pp = partial + v * RED_BLOCKS;
+    double acc = 0;
+    for (int i = threadIdx.x; i < jobs.nb[v]; i += BLK) acc += pp[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) jobs.out[v][jobs.slot[v]] = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+  }
+  if (jobs.ha) {  // the controller's scalars to pinned host memory (thread 0 wrote the sums: ordered by the barrier)
+    __threadfence();
+    const int t = threadIdx.x;
+    if (t < jobs.na) jobs.ha[t] = jobs.pa[t];
+    if (t < jobs.nb2) jobs.hb[t] = jobs.pb[t];
+    if (t == 0 && jobs.pflag) jobs.hflag[0] = jobs.pflag[0];
+  }
 }
 
 __global__ __launch_bounds__(BLK) void k_axpy(int64_t n, const double *__restrict__ x, const double *__restrict__ d,
@@ -1199,11 +1214,16 @@ int launch_cam_blocks(ba_problem *p, const double *d_J, const double *d_r, doubl
 }
 
 int launch_schur_prep(ba_problem *p, double lambda, const double *d_Hpp, const double *d_gp, double *d_Uinv,
-                      double *d_u, hipStream_t st, const double *d_lambda, const double *d_damp) {
-  if (p->npnts == 0) return BA_OK;
+                      double *d_u, hipStream_t st, const double *d_lambda, const double *d_damp, double *d_lambda_copy,
+                      double *d_zero, int64_t nzero) {
+  if (p->npnts == 0) {
+    if (d_lambda_copy) BA_HIP_CHECK(hipMemcpyAsync(d_lambda_copy, d_lambda, sizeof(double), hipMemcpyDefault, st));
+    if (nzero > 0) BA_HIP_CHECK(hipMemsetAsync(d_zero, 0, (size_t)nzero * sizeof(double), st));
+    return BA_OK;
+  }
   ProfScope ps(p, PC_SCHUR_PREP, st);
   hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(p->npnts, BLK)), dim3(BLK), 0, st, p->npnts, lambda, d_lambda, d_Hpp,
-                     d_gp, d_Uinv, d_u, d_damp);
+                     d_gp, d_Uinv, d_u, d_damp, d_lambda_copy, d_zero, nzero);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
@@ -1406,7 +1426,7 @@ int launch_sumsq_multi(ba_problem *p, SumsqJobs *jobs, double *d_partial_multi, 
     jobs->nb[v] = nb;
   }
   hipLaunchKernelGGL(k_sumsq_multi, dim3(jobs->count * RED_BLOCKS), dim3(BLK), 0, st, *jobs, d_partial_multi);
-  hipLaunchKernelGGL(k_sum_partials_multi, dim3(jobs->count), dim3(BLK), 0, st, *jobs, (const double *)d_partial_multi);
+  hipLaunchKernelGGL(k_sum_partials_multi, dim3(1), dim3(BLK), 0, st, *jobs, (const double *)d_partial_multi);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }

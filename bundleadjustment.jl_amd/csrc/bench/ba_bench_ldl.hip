@@ -37,6 +37,8 @@ static int set_bench_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 33>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 9>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
   return BA_OK;
@@ -79,6 +81,7 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
       case 17: hipLaunchKernelGGL((k_ldl_update<double, 1, 17>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       case 32: hipLaunchKernelGGL((k_ldl_update<double, 1, 32>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
       case 33: hipLaunchKernelGGL((k_ldl_update<double, 1, 33>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
+      case 64: hipLaunchKernelGGL((k_ldl_update<double, 1, 64>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       case 9: hipLaunchKernelGGL((k_ldl_update<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       default: hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr);
     }
