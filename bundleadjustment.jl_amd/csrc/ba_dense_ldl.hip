@@ -478,6 +478,7 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
       if (stamps && lane == 0) stamps[6 + s * 8 + wv] = __builtin_amdgcn_s_memtime() - c0;  // busy time of this wave
       __syncthreads();
       STAMP(1)
+      if (stamps) c0 = __builtin_amdgcn_s_memtime();
       row_solves(s + 1);
       if (wv == 3 && lane < 16) inv16(s + 1);
       if (h >= 0) {
@@ -487,6 +488,7 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
           else f_task(s, nP - nfix + (t - (s + 1)));
         }
       }
+      if (stamps && lane == 0) stamps[62 + s * 8 + wv] = __builtin_amdgcn_s_memtime() - c0;  // busy time in A(s+1)
       __syncthreads();
       STAMP(2)
     }

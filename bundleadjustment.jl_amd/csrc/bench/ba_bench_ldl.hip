@@ -189,8 +189,8 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
   BA_HIP_CHECK(hipMemset(Li, 0, NB * NB * sizeof(double)));
   BA_HIP_CHECK(hipMalloc((void **)&D, NB * sizeof(double)));
   BA_HIP_CHECK(hipMalloc((void **)&flag, sizeof(int)));
-  BA_HIP_CHECK(hipMalloc((void **)&st, 62 * sizeof(unsigned long long)));
-  BA_HIP_CHECK(hipMemset(st, 0, 62 * sizeof(unsigned long long)));
+  BA_HIP_CHECK(hipMalloc((void **)&st, 118 * sizeof(unsigned long long)));
+  BA_HIP_CHECK(hipMemset(st, 0, 118 * sizeof(unsigned long long)));
   std::vector<double> h((size_t)NB * NB, 0.0);
   for (int i = 0; i < NB; i++)
     for (int j = 0; j <= i; j++) h[(size_t)i * NB + j] = (i == j) ? 300.0 + i : 1.0 / (1 + i + j);
@@ -219,9 +219,9 @@ extern "C" int ba_debug_diag_stamps(double *cycles6, double *ms_out) {
     mix(dv);
     fprintf(stderr, "[diag] output fingerprint %016llx  D[0] %.17g D[127] %.17g Linv[127][0] %.17g\n", hsh, dv[0], dv[127], li[(size_t)127 * NB]);
   }
-  unsigned long long hs[62];
+  unsigned long long hs[118];
   BA_HIP_CHECK(hipMemcpy(hs, st, sizeof hs, hipMemcpyDeviceToHost));
-  for (int q = 0; q < 62; q++) cycles6[q] = (double)hs[q];  // 6 phases, then the busy time of wave w in stage s at [6 + 8 s + w]
+  for (int q = 0; q < 118; q++) cycles6[q] = (double)hs[q];  // 6 phases, then the busy time of wave w in phase P(s) at [6 + 8 s + w] and in phase A(s+1) at [62 + 8 s + w]
   *ms_out = ms;
   (void)hipFree(S); (void)hipFree(Li); (void)hipFree(D); (void)hipFree(flag); (void)hipFree(st);
   return BA_OK;
