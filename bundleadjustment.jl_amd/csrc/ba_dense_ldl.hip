@@ -435,6 +435,9 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
     //                         U(I,J,s-1), I > s, J < s;  F(I,J,s), J > s+1, as far as three rounds of tasks go;
     //   A(s+1), the five waves beside row solves and inv16:  U(s+1,J,s), J <= s (X(s+1,.) is due in P(s+1));  the rest of F.
     // Every block still receives its terms in the order K = 0, 1, ...: same bits as the four-wave form below.
+    // (Tried and dropped: a worker's tasks two at a time -- two independent accumulators, loads issued together, the matrix
+    // instructions of one chain in the other's latency: 36.0 us against 34.3, the workers' busy time went UP by ~10 %.  The
+    // tasks are not waiting for their own latency: eight waves share one LDS pipe (~10 KB of operand traffic per task).)
     constexpr int CAP = 3 * NWK - 1;  // the wave that shares wave 0's SIMD sits out the third round (it was the last to
                                       // arrive by ~700 cycles per stage)
     // workers: the wave that shares wave 0's SIMD comes last; helpers of A: the two waves of the free SIMD first, the
