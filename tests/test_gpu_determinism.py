@@ -73,34 +73,38 @@ def test_lm_step_twice_same_bits_venice_scaled(ba, gpu_ok):
 def test_prefetched_trial_step_same_rows_as_two_submissions(ba, gpu_ok, variant):
     """Recorded launch sequences (small problems): after an accepted step the refresh of J and the NEXT trial step are
     submitted together and waited for once (ba_lm.hip, accept_refresh_and_trial).  With BA_LM_PREFETCH=0 every sequence
-    is submitted and waited for on its own, as before.  Both forms must produce the same history rows, the same counters
-    (a prefetched step that the stopping tests then drop is not counted) and the same bits in x."""
+    is submitted and waited for on its own, as before; with BA_LM_GRAPH=0 nothing is recorded at all (plain launches, the
+    scalars fetched by a launch of their own).  All three forms must produce the same history rows, the same counters (a
+    prefetched step that the stopping tests then drop is not counted) and the same bits in x."""
     p = ba.synthetic.make_named("ladybug-49")
     arrays = ba.synthetic.as_arrays(p)
     args = {"lm.jl": ("None", False), "LevenbergMarquardt.jl": ("None",), "lm.jl linesearch": ("J", True)}[variant]
+    forms = [("prefetched", {}), ("separate submissions", {"BA_LM_PREFETCH": "0"}), ("plain launches", {"BA_LM_GRAPH": "0"})]
     out = []
-    for pre in ("1", "0"):
-        os.environ["BA_LM_PREFETCH"] = pre
+    for _, env in forms:
+        os.environ.update(env)
         try:
             m = ba.BALNLPModel(arrays=arrays)
             st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "LDL", "AMD", *args, ite_max=25, atol=0.0, rtol=0.0,
                                         oatol=0.0, ortol=0.0)  # (no early first-order / objective stop: a run of 25 iterations)
             m.close()
         finally:
-            del os.environ["BA_LM_PREFETCH"]
+            for k in env:
+                del os.environ[k]
         out.append(st)
-    a, b = out
+    a = out[0]
     assert a.n_accepted >= 5, f"{variant}: only {a.n_accepted} accepted steps -- the prefetch never ran"
-    assert (a.status, a.iter, a.n_accepted, a.n_rejected, a.n_factor, a.n_jacobian, a.n_residual) == \
-           (b.status, b.iter, b.n_accepted, b.n_rejected, b.n_factor, b.n_jacobian, b.n_residual), \
-        f"{variant}: counters differ: prefetch {a.status, a.iter, a.n_accepted, a.n_rejected, a.n_factor, a.n_jacobian, a.n_residual} " \
-        f"vs plain {b.status, b.iter, b.n_accepted, b.n_rejected, b.n_factor, b.n_jacobian, b.n_residual}"
-    la, lb = np.array(a.log, dtype=np.float64), np.array(b.log, dtype=np.float64)  # (a NaN rho equals a NaN rho here)
-    same = la.shape == lb.shape and np.array_equal(la, lb, equal_nan=True)
-    assert same, f"{variant}: history rows differ ({la.shape} vs {lb.shape}), first at row " \
-                 f"{next((i for i in range(min(len(la), len(lb))) if not np.array_equal(la[i], lb[i], equal_nan=True)), min(len(la), len(lb)))}"
-    rep = bits_report(a.solution, b.solution, f"{variant}: solution with prefetched trial steps vs plain submissions")
-    assert not rep, rep
+    la = np.array(a.log, dtype=np.float64)  # (a NaN rho equals a NaN rho below)
+    for (name, _), b in zip(forms[1:], out[1:]):
+        ca = (a.status, a.iter, a.n_accepted, a.n_rejected, a.n_factor, a.n_jacobian, a.n_residual)
+        cb = (b.status, b.iter, b.n_accepted, b.n_rejected, b.n_factor, b.n_jacobian, b.n_residual)
+        assert ca == cb, f"{variant}: counters differ: prefetched {ca} vs {name} {cb}"
+        lb = np.array(b.log, dtype=np.float64)
+        same = la.shape == lb.shape and np.array_equal(la, lb, equal_nan=True)
+        assert same, f"{variant}: history rows of prefetched vs {name} differ ({la.shape} vs {lb.shape}), first at row " \
+                     f"{next((i for i in range(min(len(la), len(lb))) if not np.array_equal(la[i], lb[i], equal_nan=True)), min(len(la), len(lb)))}"
+        rep = bits_report(a.solution, b.solution, f"{variant}: solution, prefetched trial steps vs {name}")
+        assert not rep, rep
 
 # ---- several ranks in one process over the stream-ordered loopback transport ------------------------------------------------
 @pytest.fixture(scope="module")
