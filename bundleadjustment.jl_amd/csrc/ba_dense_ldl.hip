@@ -57,16 +57,14 @@ constexpr size_t GEMM_LDS_ELEMS = (size_t)(DBUF ? 2 : 1) * 2 * NB * LDK;
 
 
 // ---- diagonal tile ---------------------------------------------------------------------------------------------
-// One workgroup (4 waves) factors the 128x128 tile in LDS as 8x8 blocks of 16x16:
+// One workgroup factors the 128x128 tile in LDS as 8x8 blocks of 16x16:
 //   for each block column jb: unblocked LDL' of the 16x16 diagonal block (one wave, registers), the rows below it by
 //   forward substitution, one row per thread (kept unscaled: X = L D), trailing blocks C(I,J) -= X(I) (X(J) D^-1)' by
-//   MFMA -- with a look-ahead of one block column (see diag_tile);
-// then the eight 16x16 unit-lower inverses and the full unit-lower inverse of the tile by block forward substitution
-// (MFMA), stored transposed in the upper triangle of the LDS image.  Writes the inverse's lower triangle and D; the
-// factored tile itself is not written back (nothing reads it).
-#ifndef BA_DIAG_EXP
-#define BA_DIAG_EXP 0
-#endif
+//   MFMA -- with a look-ahead of one block column;
+// and BESIDE that (round 3; see diag_tile) the eight 16x16 unit-lower inverses and the full unit-lower inverse of the tile,
+// right-looking, in the strict upper block triangle of the LDS image.  Every finished block of the inverse goes to global
+// memory at once; the factored tile itself is not written back (nothing reads it).  k_ldl_diag runs eight waves (two
+// phases per block column), the fused pair kernel k_ldl_pairdiag four (three phases).
 constexpr int LDA2 = 130;  // row stride 260 dwords = 4 mod 64: conflict-free MFMA operand reads
 constexpr int XDL = 18;
 constexpr int L16S = 18;   // row stride of the 16x16 multiplier block: 16-byte aligned rows for the row solves' paired reads
@@ -376,7 +374,7 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
 #pragma unroll
       for (int i = m + 1; i < 16; i++) sacc[i] += col[i] * y;
       xj[m * XDL + c] = xv;
-      if (!(BA_DIAG_EXP & 4)) Linv_k[(o + m) * NB + o + c] = xv;
+      Linv_k[(o + m) * NB + o + c] = xv;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = m + 2; i < 16; i++) col[i] = nxt[i];
@@ -392,7 +390,7 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       a[(16 * J + fr) * LDA2 + 16 * I + RT<T>::row(lane, g)] = -out[g];
-      if (!(BA_DIAG_EXP & 4)) Linv_k[(16 * I + RT<T>::row(lane, g)) * NB + 16 * J + fr] = -out[g];
+      Linv_k[(16 * I + RT<T>::row(lane, g)) * NB + 16 * J + fr] = -out[g];
     }
   };
   auto inv_update = [&](int I, int J, int K) {  // acc(I,J) += L(I,K) X(K,J)
@@ -423,7 +421,7 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
   __syncthreads();
   STAMP(1)
   row_solves(0);
-  if (!(BA_DIAG_EXP & 1) && wv == 3 && lane < 16) inv16(0);
+  if (wv == 3 && lane < 16) inv16(0);
   __syncthreads();
   STAMP(2)
   if constexpr (NW == 8) {
@@ -499,17 +497,17 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
     for (int jb = 0; jb < 7; jb++) {
       for (int t = wv; t < 7; t += NW) {  // seven tasks: block column jb + 1 of the factorisation, block row jb of the inverse
         if (t < 7 - jb) block_update(jb, jb + 1 + t, jb + 1);
-        else if (!(BA_DIAG_EXP & 2)) inv_finalize(jb, t - (7 - jb));
+        else inv_finalize(jb, t - (7 - jb));
       }
       __syncthreads();
       STAMP(3)
       unsigned long long c0 = 0;
       if (stamps) c0 = __builtin_amdgcn_s_memtime();
       if (wv == 0) {
-        if (!(BA_DIAG_EXP & 8)) do_pivots(jb + 1);
+        do_pivots(jb + 1);
       } else {
         // trailing blocks (I, J), jb + 2 <= J <= I < 8, of the factorisation, then the inverse's (I, J), I > jb >= J
-        const int mb = 6 - jb, nblk = mb * (mb + 1) / 2, ninv = (BA_DIAG_EXP & 2) ? 0 : (7 - jb) * (jb + 1);
+        const int mb = 6 - jb, nblk = mb * (mb + 1) / 2, ninv = (7 - jb) * (jb + 1);
         for (int t = wv - 1; t < nblk + ninv; t += NWK) {
           if (t < nblk) {
             int ii = 0;
@@ -526,7 +524,7 @@ __device__ __forceinline__ void diag_tile(T *__restrict__ Skk, T *__restrict__ L
       __syncthreads();
       STAMP(1)
       row_solves(jb + 1);
-      if (!(BA_DIAG_EXP & 1) && wv == 3 && lane < 16) inv16(jb + 1);
+      if (wv == 3 && lane < 16) inv16(jb + 1);
       __syncthreads();
       STAMP(2)
     }

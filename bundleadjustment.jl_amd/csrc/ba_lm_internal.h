@@ -115,10 +115,9 @@ int launch_model_sq(ba_problem *p, const double *d_J, const double *d_r, const d
                     double *d_scal, int slot, hipStream_t st, double cr = 1.0);
 int launch_sumsq(ba_problem *p, int64_t n, const double *d_v, double *d_partial, double *d_scal, int slot,
                  hipStream_t st);
-// d_a[0..na), d_b[0..nb), d_flag[0] (optional) -> pinned host buffers, one launch; a pinned host scalar -> device
+// d_a[0..na), d_b[0..nb), d_flag[0] (optional) -> pinned host buffers, one launch
 int launch_publish(const double *d_a, int na, double *h_a, const double *d_b, int nb, double *h_b, const int *d_flag, int *h_flag,
                    hipStream_t st);
-int launch_fetch_scalar(const double *h, double *d, hipStream_t st);
 int launch_sumsq_multi(ba_problem *p, SumsqJobs *jobs, double *d_partial_multi /* SUMSQ_JOBS RED_BLOCKS */, hipStream_t st);
 int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st);
 int launch_hcc_diag(ba_problem *p, const double *d_Hcc, double *d_hdiag, hipStream_t st);

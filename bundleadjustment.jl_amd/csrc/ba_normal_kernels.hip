@@ -1431,9 +1431,10 @@ int launch_sumsq_multi(ba_problem *p, SumsqJobs *jobs, double *d_partial_multi, 
   return BA_OK;
 }
 
-// The LM controller's scalars to pinned host memory and the damping from it, by kernels that address the host buffers
-// directly (hipHostMalloc memory is mapped): in a recorded launch sequence each of the former three + one copy nodes cost a
-// dispatch of ~5 us of its own.
+// The LM controller's scalars to pinned host memory by a kernel that addresses the host buffers directly (hipHostMalloc
+// memory is mapped): in a recorded launch sequence each of the former three copy nodes cost a dispatch of ~5 us of its own.
+// (Recorded sequences publish from their last reduction kernel instead, k_sum_partials_multi; the damping travels the other
+// way inside k_schur_prep.)
 __global__ void k_publish(const double *__restrict__ a, int na, double *__restrict__ ha, const double *__restrict__ b, int nb,
                           double *__restrict__ hb, const int *__restrict__ flag, int *__restrict__ hflag) {
   const int t = threadIdx.x;
@@ -1441,7 +1442,6 @@ __global__ void k_publish(const double *__restrict__ a, int na, double *__restri
   if (t < nb) hb[t] = b[t];
   if (t == 0 && flag) hflag[0] = flag[0];
 }
-__global__ void k_fetch_scalar(const double *__restrict__ h, double *__restrict__ d) { d[0] = h[0]; }
 
 int launch_publish(const double *d_a, int na, double *h_a, const double *d_b, int nb, double *h_b, const int *d_flag, int *h_flag,
                    hipStream_t st) {
@@ -1450,11 +1450,6 @@ int launch_publish(const double *d_a, int na, double *h_a, const double *d_b, in
     return BA_ERR_ARG;
   }
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, d_a, na, h_a, d_b, nb, h_b, d_flag, h_flag);
-  BA_HIP_CHECK(hipGetLastError());
-  return BA_OK;
-}
-int launch_fetch_scalar(const double *h, double *d, hipStream_t st) {
-  hipLaunchKernelGGL(k_fetch_scalar, dim3(1), dim3(1), 0, st, h, d);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
