@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--locality", type=float, default=None,
                     help="cameras of a point drawn from a window of this fraction of the cameras: block-banded reduced camera "
                          "matrix (synthetic.make_problem); default: every camera pair shares points, dense S")
+    ap.add_argument("--shuffle-cameras", action="store_true",
+                    help="renumber the cameras at random (synthetic.shuffle_cameras): what `perm` has to undo (not the headline configuration)")
+    ap.add_argument("--perm", choices=["AMD", "Metis", "natural"], default="AMD",
+                    help="fill-reducing camera ordering of the reduced camera system (src/lm.jl:84-88); natural = the caller's numbering")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-full", default="dubrovnik-356",
@@ -80,11 +84,12 @@ def parse():
 
 FACTO_TYPE = None  # set from --facto-type
 FACTO, PCG_TOL = "LDL", None  # set from --facto / --pcg-tol
+PERM = "AMD"                   # set from --perm
 
 
 def lm_fixed_iterations(ba, fr, k, x=None):
     """exactly k iterations of lm.jl: every stopping test disabled except the iteration cap"""
-    return ba.Levenberg_Marquardt(fr, FACTO, "AMD", "None", False, x=x, ite_max=k - 1, restol=0.0, satol=0.0, srtol=0.0,
+    return ba.Levenberg_Marquardt(fr, FACTO, PERM, "None", False, x=x, ite_max=k - 1, restol=0.0, satol=0.0, srtol=0.0,
                                   oatol=0.0, ortol=0.0, atol=0.0, rtol=0.0, log=False, facto_type=FACTO_TYPE, pcg_tol=PCG_TOL)
 
 
@@ -104,8 +109,9 @@ def spawn_ranks(args):
 
 
 def main():
-    global FACTO_TYPE, FACTO, PCG_TOL
+    global FACTO_TYPE, FACTO, PCG_TOL, PERM
     args = parse()
+    PERM = args.perm
     if args.facto == "pcg":
         FACTO, PCG_TOL = "PCG", args.pcg_tol
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -135,6 +141,8 @@ def main():
     # ---- workload ---------------------------------------------------------------------------------------------------
     t0 = time.time()
     prob = ba.synthetic.make_named(args.workload, scale=args.scale, locality=args.locality)
+    if args.shuffle_cameras:
+        prob, _ = ba.synthetic.shuffle_cameras(prob, seed=ba.synthetic.BASE_SEED)
     arrays = ba.synthetic.as_arrays(prob)
     if world > 1:
         arrays, info = ba.parallel.shard_problem(arrays, rank, world)
@@ -358,6 +366,7 @@ def main():
                                    f"{ba.synthetic.BASE_SEED}, lm.jl variant, {FACTO}/None" + (f" (pcg_tol {PCG_TOL:g})" if FACTO == "PCG" else "") + f", facto_type {args.facto_type}, fixed {args.steps} iterations"
                                    + ("" if args.scale == 1.0 else f" SCALED x{args.scale} (debug)")
                                    + ("" if args.locality is None else f" LOCALITY {args.locality} (block-banded S; not the headline configuration)")
+                                   + (" CAMERAS RENUMBERED AT RANDOM" if args.shuffle_cameras else "") + f", perm {PERM}"
                                    + (f" EMULATED SHARD {args.emulate_shard} (one rank's compute, no communicator)" if args.emulate_shard else ""),
                        "parallelism": f"points sharded over {world} rank(s), cameras replicated"
                                       + ("" if world == 1 else "; reduced camera matrix reduced onto the owners of its tile column "
@@ -378,7 +387,7 @@ def main():
         if FACTO != "PCG":
             tf, ff, sp = ba.schur_pattern(nlp)
             full, held, staging = ba.schur_memory(nlp)
-            out["schur_pattern"] = {"tile_fill": tf, "update_tiles_over_dense": ff, "list_schedule": sp,
+            out["schur_pattern"] = {"camera_sequence": ba.schur_ordering_used(nlp)[1], "tile_fill": tf, "update_tiles_over_dense": ff, "list_schedule": sp,
                                     "tiles_full": full, "tiles_held": held, "tiles_staging": staging,
                                     "S_gib_held": held * 128 * 128 * 8 / 2 ** 30}
         if reducer is not None:

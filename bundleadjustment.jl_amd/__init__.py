@@ -13,11 +13,13 @@ except ImportError:  # pragma: no cover
     _torch = None
 from . import _lib
 from ._lib import BAError, SQDException, device_count
-from .lm import GenericExecutionStats, Levenberg_Marquardt, lm_step, schur_pattern, schur_memory
+from .lm import GenericExecutionStats, Levenberg_Marquardt, lm_step, schur_pattern, schur_memory, set_ordering, schur_ordering_used
+from ._lib import schur_ordering
 from .model import BALNLPModel, FeasibilityResidual
 from .readfiles import name, readfile
 from . import synthetic
 from . import parallel
 
 __all__ = ["BALNLPModel", "FeasibilityResidual", "Levenberg_Marquardt", "GenericExecutionStats", "readfile", "name",
-           "BAError", "SQDException", "device_count", "synthetic", "parallel", "lm_step", "schur_pattern", "schur_memory"]
+           "BAError", "SQDException", "device_count", "synthetic", "parallel", "lm_step", "schur_pattern", "schur_memory", "set_ordering", "schur_ordering_used",
+           "schur_ordering"]

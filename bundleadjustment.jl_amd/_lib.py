@@ -31,7 +31,7 @@ class LMOpts(C.Structure):
                 ("restol", C.c_double), ("satol", C.c_double), ("srtol", C.c_double), ("oatol", C.c_double),
                 ("ortol", C.c_double), ("atol", C.c_double), ("rtol", C.c_double),
                 ("nu_d", C.c_double), ("nu_m", C.c_double), ("lam", C.c_double), ("delta_d", C.c_double),
-                ("max_time", C.c_double), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int), ("reserved1", C.c_int)]
+                ("max_time", C.c_double), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int), ("perm", C.c_int)]
 
 
 class LMStats(C.Structure):
@@ -55,7 +55,7 @@ SYMBOLS = [
     "ba_jac_structure_dev", "ba_jac_coord_dev", "ba_jac_coord_f32_dev", "ba_jtr_dev", "ba_dev_malloc", "ba_dev_free",
     "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_memcpy_h2d_on", "ba_memcpy_d2h_on", "ba_synchronize", "ba_lm_solve", "ba_comm_get_unique_id", "ba_lm_set_comm_rccl",
     "ba_lm_set_comm_hook", "ba_comm_stats", "ba_dist_layout",
-    "ba_lm_step", "ba_lm_step_f32", "ba_lm_step_pcg", "ba_lm_schur_pattern", "ba_lm_schur_memory", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
+    "ba_lm_step", "ba_lm_step_f32", "ba_lm_step_pcg", "ba_lm_schur_pattern", "ba_lm_schur_memory", "ba_schur_ordering", "ba_lm_set_ordering", "ba_lm_schur_ordering", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
 ]
 
 _lib = None
@@ -105,6 +105,9 @@ def lib():
     L.ba_lm_step_pcg.argtypes = [vp, vp, f64, f64, C.c_int, vp, C.POINTER(f64), vp, C.POINTER(C.c_int)]
     L.ba_lm_schur_pattern.argtypes = [vp, C.POINTER(f64), C.POINTER(f64), C.POINTER(C.c_int)]
     L.ba_lm_schur_memory.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.ba_schur_ordering.argtypes = [i64, i64, i64, vp, vp, C.c_int, vp, C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]
+    L.ba_lm_set_ordering.argtypes = [vp, C.c_int]
+    L.ba_lm_schur_ordering.argtypes = [vp, vp, C.POINTER(C.c_char_p)]
     L.ba_profile_enable.argtypes = [vp, C.c_int]
     L.ba_profile_reset.argtypes = [vp]
     L.ba_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(f64), C.POINTER(i64), C.POINTER(C.c_int)]
@@ -135,6 +138,22 @@ def device_count():
     except OSError:
         return 0
     return n.value if rc == BA_OK else 0
+
+
+ORDERINGS = {"AMD": 0, "Metis": 1, "natural": 2}
+
+
+def schur_ordering(cam_idx1, pnt_idx1, ncams, npnts, method="AMD"):
+    """Fill-reducing camera ordering of a problem (`perm` of src/lm.jl:84-88 applied to the reduced camera system) and the
+    tile fill it leaves: (perm1, tile_fill, flop_fill, block_fill); perm1[k] = 1-based camera at block row k of S.  Host
+    only: needs no device."""
+    cam = np.ascontiguousarray(cam_idx1, dtype=np.int64)
+    pnt = np.ascontiguousarray(pnt_idx1, dtype=np.int64)
+    perm = np.zeros(int(ncams), dtype=np.int64)
+    tf, ff, bf = C.c_double(0), C.c_double(0), C.c_double(0)
+    check(lib().ba_schur_ordering(int(ncams), int(npnts), len(cam), ptr(cam), ptr(pnt), ORDERINGS[method], ptr(perm),
+                                  C.byref(tf), C.byref(ff), C.byref(bf)))
+    return perm, tf.value, ff.value, bf.value
 
 
 def dense_ldl_solve(A, b, device=0, f32=False):

@@ -367,3 +367,20 @@ extern "C" int ba_profile_get(ba_problem *p, int cap, const char **names, double
   }
   return BA_OK;
 }
+
+// src/lm.jl:84-88 (`perm`): the camera ordering of a problem and the tile fill it leaves -- host only (ba_order.cpp)
+int schur_ordering_host(int64_t ncams, int64_t npnts, int64_t nobs, const int64_t *cam_idx1, const int64_t *pnt_idx1, int method,
+                        int nb, int64_t *perm1, double *tile_fill, double *flop_fill, double *block_fill);
+extern "C" int ba_schur_ordering(int64_t ncams, int64_t npnts, int64_t nobs, const int64_t *cam_idx1, const int64_t *pnt_idx1,
+                                 int method, int64_t *perm1, double *tile_fill, double *flop_fill, double *block_fill) {
+  if (method < 0 || method > 2) {
+    ba_set_error("ba_schur_ordering: method must be 0 (:AMD), 1 (:Metis) or 2 (the caller's numbering)");
+    return BA_ERR_ARG;
+  }
+  const int rc = schur_ordering_host(ncams, npnts, nobs, cam_idx1, pnt_idx1, method, NB, perm1, tile_fill, flop_fill, block_fill);
+  if (rc != 0) {
+    ba_set_error(rc == 1 ? "ba_schur_ordering: bad sizes or index out of range" : "ba_schur_ordering: internal error (incomplete sequence)");
+    return BA_ERR_ARG;
+  }
+  return BA_OK;
+}

@@ -1895,56 +1895,7 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
 // The numeric phase is the in-order pair schedule with row lists: diag(k), panel solve of column k over {k+1} + U_q,
 // column update, diag(k+1), panel solve of column k+1 over U_q, pair update over the lower tiles of U_q x U_q.  Tiles
 // outside the pattern are never read or written: they hold the zeros of the assembly's memset.
-void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ /* nt x nt, lower, row-major; gets the fill */, TilePattern *out) {
-  const int npairs = (int)((nt + 1) / 2);
-  out->nt = nt;
-  out->prow_ptr.assign(1, 0);
-  out->prow.clear();
-  double tiles_sparse = 0, tiles_dense = 0;
-  std::vector<int> U;
-  for (int q = 0; q < npairs; q++) {
-    const int k = 2 * q;
-    U.clear();
-    for (int64_t i = k + 2; i < nt; i++)
-      if (occ[(size_t)(i * nt + k)] || (k + 1 < nt && occ[(size_t)(i * nt + k + 1)])) U.push_back((int)i);
-    for (size_t a = 0; a < U.size(); a++)
-      for (size_t b = 0; b <= a; b++) occ[(size_t)((int64_t)U[a] * nt + U[b])] = 1;
-    if (k + 1 < nt) {
-      occ[(size_t)((int64_t)(k + 1) * nt + k)] = 1;
-      out->prow.push_back(k + 1);  // the list of pair q starts with tile row k+1 (the panel solve of column k needs it)
-      for (int i : U) {
-        occ[(size_t)((int64_t)i * nt + k)] = 1;  // union of the two columns' rows
-        occ[(size_t)((int64_t)i * nt + k + 1)] = 1;
-      }
-    }
-    for (int i : U) out->prow.push_back(i);
-    out->prow_ptr.push_back((int)out->prow.size());
-    const double m = (double)(nt - k - 2 > 0 ? nt - k - 2 : 0), u = (double)U.size();
-    tiles_sparse += u * (u + 1) / 2;
-    tiles_dense += m * (m + 1) / 2;
-  }
-  out->lcol_ptr.assign(1, 0);
-  out->lcol.clear();
-  int64_t ntiles = 0;
-  for (int64_t i = 0; i < nt; i++) {
-    for (int64_t j = 0; j < i; j++)
-      if (occ[(size_t)(i * nt + j)]) {
-        out->lcol.push_back((int)j);
-        ntiles++;
-      }
-    out->lcol_ptr.push_back((int)out->lcol.size());
-  }
-  // backward sweep two tile rows per launch (rows k, k-1 for k = nt-1, nt-3, ...): the union of their pattern columns < k-1
-  out->lpair_ptr.assign(1, 0);
-  out->lpair.clear();
-  for (int64_t k = nt - 1; k >= 1; k -= 2) {
-    for (int64_t j = 0; j < k - 1; j++)
-      if (occ[(size_t)(k * nt + j)] || occ[(size_t)((k - 1) * nt + j)]) out->lpair.push_back((int)j);
-    out->lpair_ptr.push_back((int)out->lpair.size());
-  }
-  out->tile_fill = (double)(ntiles + nt) / ((double)nt * (double)(nt + 1) / 2);
-  out->flop_fill = tiles_dense > 0 ? tiles_sparse / tiles_dense : 1.0;
-}
+// (the symbolic phase, tile_pattern_build, is host-only code: ba_order.cpp)
 
 template <typename T>
 int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/ba_hip.h"
+#include "ba_order.h"  // TilePattern, camera orderings (host only)
 
 void ba_set_error(const char *fmt, ...);
 
@@ -69,16 +70,6 @@ extern const char *const kProfNames[PC_COUNT];
 struct ProfSlot {
   double ms = 0;
   int64_t calls = 0;
-};
-
-// tile pattern of a block-sparse reduced camera system after the symbolic factorisation (ba_dense_ldl.hip)
-struct TilePattern {
-  int64_t nt = 0;
-  std::vector<int> prow_ptr, prow;  // pair q: [k+1] + the tile rows of its pattern (k = 2q), ascending
-  std::vector<int> lcol_ptr, lcol;  // tile row i: the tile columns j < i of its pattern, ascending
-  std::vector<int> lpair_ptr, lpair;  // launch q of the paired backward sweep (rows k = nt-1-2q, k-1): union of their columns < k-1
-  double tile_fill = 1.0;           // pattern tiles (with fill) / all lower tiles
-  double flop_fill = 1.0;           // trailing-update tiles of the pattern / of the dense factorisation
 };
 
 template <typename T>
@@ -219,9 +210,8 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
 // No fused forward substitution: call dense_ldl_solve(..., forward_done = false).
 template <typename T>
 int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, T *d_b = nullptr);
-// block-sparse S: symbolic factorisation of the tile occupancy `occ` (nt x nt, lower, row-major; receives the fill) per
-// tile column pair, and its use by a workspace (null: dense).  The pattern object must outlive the workspace.
-void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ, TilePattern *out);
+// block-sparse S: the use of a tile pattern (tile_pattern_build, ba_order.h) by a workspace (null: dense).  The pattern object
+// must outlive the workspace.
 template <typename T>
 int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat);
 // solve S x = b for one right-hand side held in d_b (length nt*NB, overwritten by x)

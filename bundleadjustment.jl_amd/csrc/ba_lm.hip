@@ -46,10 +46,17 @@ int upload_vec(T **d, const std::vector<T> &h) {
   return BA_OK;
 }
 
-// Build the (camera_a >= camera_b)-sorted list of observation pairs sharing a point.
-int build_tasks(ba_problem *p, SchurTasks *T) {
+// Build the (camera_a >= camera_b)-sorted list of observation pairs sharing a point.  "Camera" here is the BLOCK ROW of S the
+// camera sits at: pos[c] under a fill-reducing camera ordering (empty: c itself).
+int build_tasks(ba_problem *p, SchurTasks *T, const std::vector<int> &pos) {
   const int64_t ncams = p->ncams, npnts = p->npnts;
-  const std::vector<int> &cam = p->h_cam0, &ptr = p->h_pt_ptr, &obs = p->h_pt_obs;
+  const std::vector<int> &ptr = p->h_pt_ptr, &obs = p->h_pt_obs;
+  std::vector<int> cam_at;
+  if (!pos.empty()) {
+    cam_at.resize(p->h_cam0.size());
+    for (size_t o = 0; o < cam_at.size(); o++) cam_at[o] = pos[(size_t)p->h_cam0[o]];
+  }
+  const std::vector<int> &cam = pos.empty() ? p->h_cam0 : cam_at;
   // pass 1: tasks per camera_a
   std::vector<int64_t> ca_ptr((size_t)ncams + 1, 0);
   int64_t ntasks = 0;
@@ -191,6 +198,12 @@ struct LMWorkFull : LMWork {
   int64_t stage_tiles = 0;
   TilePattern pattern;       // tile pattern of S after the symbolic factorisation (ensure_dense)
   bool use_pattern = false;  // the block-sparse list schedule is in use on this handle
+  // fill-reducing camera ordering of the reduced camera system (`perm` of the reference's solvers, src/lm.jl:84-88): the
+  // method asked for, the camera sequence it gave (block row k of S holds camera h_cam_perm[k]; empty: the caller's
+  // numbering), the name of the candidate that won
+  int order_method = BA_ORDER_AMD;
+  std::vector<int> h_cam_perm;
+  const char *order_name = "natural";
   // facto_type = Float32 (src/lm.jl:170-173): Float32 copy of the reduced camera system, allocated on first use
   DenseLDLT<float> ldl32;
   float *rhs32 = nullptr;
@@ -402,11 +415,47 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
   return BA_OK;
 }
 
+// Fill-reducing ordering of the cameras inside the reduced camera system -- what `perm` asks of the reference's sparse
+// LDL' (amd(A) / Metis.permutation, src/lm.jl:84-88, consumed by ldl_analyse, src/ldl_aux.jl:246-283).  The tile pattern of S
+// depends on how the cameras are numbered; a BAL file promises nothing about that.  Cameras keep their numbers everywhere
+// else (x, J, Hcc, gc): only S, its right-hand side and its solution live in the new order (SchurTasks::cam_of / pos).
+// pos_out: block row of every camera, empty when the caller's numbering stays.
+static int order_cameras(ba_problem *p, LMWorkFull *w, std::vector<int> *pos_out) {
+  pos_out->clear();
+  w->h_cam_perm.clear();
+  w->order_name = "natural";
+  int method = w->order_method;
+  if (const char *e = getenv("BA_CAM_ORDER")) {  // amd | metis | natural: overrides the handle's setting (experiments)
+    method = e[0] == 'n' ? BA_ORDER_NATURAL : (e[0] == 'm' ? BA_ORDER_METIS : BA_ORDER_AMD);
+  }
+  const int64_t n = p->ncams;
+  if (method == BA_ORDER_NATURAL || n < 2 * (NB / 9) || p->comm.active()) return BA_OK;  // (fewer cameras than two tiles hold: dense anyway)
+  CamGraph g;
+  cam_graph_build(n, p->npnts, p->h_pt_ptr.data(), p->h_pt_obs.data(), p->h_cam0.data(), &g);
+  // more than half of all camera pairs share points: S is dense at tile granularity whatever the order
+  if ((double)g.edges() > 0.25 * (double)n * (double)(n - 1)) return BA_OK;
+  std::vector<int> perm;
+  const char *name = "natural";
+  cam_order(g, method, NB, &perm, &name);
+  bool identity = true;
+  for (int64_t k = 0; k < n && identity; k++) identity = perm[(size_t)k] == (int)k;
+  if (identity) return BA_OK;
+  w->order_name = name;
+  pos_out->resize((size_t)n);
+  for (int64_t k = 0; k < n; k++) (*pos_out)[(size_t)perm[(size_t)k]] = (int)k;
+  BA_CHECK(upload_vec(&w->tasks.cam_of, perm));
+  BA_CHECK(upload_vec(&w->tasks.pos, *pos_out));
+  w->h_cam_perm.swap(perm);
+  return BA_OK;
+}
+
 // what only the direct solves need: the tiles of S, the Schur task list, the per-observation Y blocks
 static int ensure_dense(ba_problem *p, LMWorkFull *w) {
   if (w->ldl.S) return BA_OK;
   BA_CHECK(dmalloc(&w->Yobs, 6 * p->nobs));
-  BA_CHECK(build_tasks(p, &w->tasks));
+  std::vector<int> pos;
+  BA_CHECK(order_cameras(p, w, &pos));
+  BA_CHECK(build_tasks(p, &w->tasks, pos));
   // Block-sparse reduced camera system (one GPU): symbolic factorisation of the tile occupancy; the list schedule is used
   // when the pattern's trailing updates are at most 60 % of the dense factorisation's (BA_SPARSE_S=1 / 0 forces it on /
   // off).  Every camera pair sharing points (the default synthetic generator, small problems) gives flop_fill = 1: dense.
@@ -443,7 +492,7 @@ void lm_free(ba_problem *p) {
   void *ptrs[] = {w->jn2, w->dcol, w->damp, w->Jq, w->rq, w->x, w->x_trial, w->delta, w->r, w->r_trial, w->J, w->Hpp, w->gp, w->Uinv, w->u, w->Hcc,
                   w->partial, w->partial_multi, w->colscale, w->Yobs, w->s.scal_rep, w->tasks.key_ptr, w->tasks.key_ca, w->tasks.key_cb,
                   w->tasks.task_a, w->tasks.task_b, w->tasks.skey, w->tasks.skey_c0, w->tasks.chunk_t0,
-                  w->tasks.chunk_t1, w->tasks.partial, w->s.own_red ? w->s.red : nullptr};
+                  w->tasks.chunk_t1, w->tasks.partial, w->tasks.cam_of, w->tasks.pos, w->s.own_red ? w->s.red : nullptr};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   for (int q = 0; q < 2; q++) {
@@ -673,16 +722,16 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
       }
     }
     BA_HIP_CHECK(hipMemsetAsync(w->rhs, 0, (size_t)w->npad * sizeof(double), st));
-    BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
+    BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt, w->tasks.pos));
     BA_CHECK(comm_sum(p, w, w->s.off_rhs, w->npad, st));
   } else {
     BA_CHECK(launch_schur_blocks(p, &w->tasks, Jl, w->Uinv, w->Yobs, w->Hcc, lam_diag, w->ldl.S, w->ldl.col_off, w->n,
                                  p->rank == 0 ? w->npad : w->n, st, d_lambda, damp, w->ldl.s_tiles));
-    BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt));
+    BA_CHECK(launch_schur_rhs(p, Jl, rl, w->u, w->rhs, st, w->cam_pnt, w->tasks.pos));
     BA_CHECK(reduce_camera_system(p, w, st, reduce32));
   }
   if (normalize != 0) {  // :J / :A column scaling of the camera system from the GLOBAL diagonal (refresh_linearisation)
-    BA_CHECK(launch_cam_scale(p, w->hdiag, normalize == 2 ? lambda : 0.0, w->colscale, st, d_lambda));
+    BA_CHECK(launch_cam_scale(p, w->hdiag, normalize == 2 ? lambda : 0.0, w->colscale, st, d_lambda, w->tasks.pos));
     if (w->ldl.own_only)
       BA_CHECK(launch_scale_S_own(p, w->n, w->colscale, w->ldl.S, w->ldl.col_off, w->ldl.own_cols, w->ldl.own_pref,
                                   (int)w->ldl.h_own_cols.size(), w->ldl.own_range[(size_t)w->ldl.rank + 1] - w->ldl.own_range[(size_t)w->ldl.rank], st));
@@ -712,7 +761,8 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   }
   double *dc = w->delta + 3 * p->npnts;
   if (normalize != 0) BA_CHECK(launch_scale_vec(p, w->n, w->colscale, w->rhs, 1, st));  // dc = D^-1 dc'
-  BA_HIP_CHECK(hipMemcpyAsync(dc, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (w->tasks.pos) BA_CHECK(launch_gather_cams(p, w->tasks.pos, w->rhs, dc, st));  // block rows of S -> camera order
+  else BA_HIP_CHECK(hipMemcpyAsync(dc, w->rhs, (size_t)w->n * sizeof(double), hipMemcpyDeviceToDevice, st));
   // the model value of the step rides along with the back-substitution (not in the Float16 branch: its step is rescaled below)
   BA_CHECK(launch_backsub(p, Jl, w->Uinv, w->u, dc, w->delta, st, w->f16 ? nullptr : rl, w->cr0(), w->partial, w->scal, SH_MODEL,
                           &w->model_done));
@@ -968,6 +1018,45 @@ extern "C" int ba_lm_schur_pattern(ba_problem *p, double *tile_fill, double *flo
   return BA_OK;
 }
 
+// (re)select the camera ordering of the handle; structures built under another one are dropped
+static int set_ordering(ba_problem *p, int method) {
+  if (method < 0 || method > 2) {
+    ba_set_error("camera ordering: 0 (:AMD), 1 (:Metis) or 2 (the caller's numbering)");
+    return BA_ERR_ARG;
+  }
+  BA_CHECK(lm_ensure(p));
+  LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
+  if (w->order_method == method) return BA_OK;
+  if (w->ldl.S) {  // the task list, the pattern and the tiles depend on the order: start over
+    lm_free(p);
+    BA_CHECK(lm_ensure(p));
+    w = static_cast<LMWorkFull *>(p->lm);
+  }
+  w->order_method = method;
+  return BA_OK;
+}
+
+extern "C" int ba_lm_set_ordering(ba_problem *p, int method) {
+  if (!p) {
+    ba_set_error("ba_lm_set_ordering: null handle");
+    return BA_ERR_ARG;
+  }
+  BA_HIP_CHECK(hipSetDevice(p->device));
+  return set_ordering(p, method);
+}
+
+extern "C" int ba_lm_schur_ordering(ba_problem *p, int64_t *perm1, const char **name) {
+  if (!p || !p->lm || !static_cast<LMWorkFull *>(p->lm)->ldl.S) {
+    ba_set_error("ba_lm_schur_ordering: no direct solve has run on this handle yet");
+    return BA_ERR_ARG;
+  }
+  LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
+  if (perm1)
+    for (int64_t k = 0; k < p->ncams; k++) perm1[k] = (w->h_cam_perm.empty() ? k : (int64_t)w->h_cam_perm[(size_t)k]) + 1;
+  if (name) *name = w->order_name;
+  return BA_OK;
+}
+
 extern "C" int ba_lm_step_pcg(ba_problem *p, const double *x, double lambda, double tol, int max_iter, double *delta,
                               double *half_sq_model, double *jtr, int *cg_iters_out) {
   return lm_step_impl(p, x, lambda, delta, half_sq_model, jtr, false, true, tol, max_iter, cg_iters_out);
@@ -1041,9 +1130,13 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
     ba_set_error("ba_lm_solve: normalize must be 0 (:None), 1 (:J) or 2 (:A)");
     return BA_ERR_ARG;
   }
+  if (o->perm < 0 || o->perm > 2) {
+    ba_set_error("ba_lm_solve: perm must be 0 (:AMD), 1 (:Metis) or 2 (the caller's camera numbering)");
+    return BA_ERR_ARG;
+  }
   BA_HIP_CHECK(hipSetDevice(p->device));
   const double t_start = wall();
-  BA_CHECK(lm_ensure(p));
+  BA_CHECK(set_ordering(p, o->perm));  // (lm_ensure inside)
   LMWorkFull *w = static_cast<LMWorkFull *>(p->lm);
   hipStream_t st = p->stream;
   const int V = o->variant;

@@ -21,6 +21,10 @@ struct SchurTasks {
   int *chunk_t0 = nullptr, *chunk_t1 = nullptr;                   // chunks: task range
   double *partial = nullptr;                                      // nchunks x 81
   std::vector<unsigned char> tile_occ;                            // host: nt x nt lower tile occupancy of S by the keys (before fill)
+  // Fill-reducing camera ordering (ba_order.cpp): key_ca / key_cb are BLOCK ROWS of S; cam_of[k] (device; null = identity)
+  // is the camera at block row k, pos its inverse.  Only the reduced camera system lives in that order: S, its right-hand
+  // side and solution, the column scaling; x, J, Hcc, gc stay in the caller's camera order.
+  int *cam_of = nullptr, *pos = nullptr;
   std::vector<int> h_key_cb, h_skey;                              // host copies (chunked assembly of a distributed run)
 };
 
@@ -107,7 +111,8 @@ int launch_schur_chunk(ba_problem *p, const SchurTasks *T, const SchurChunk *c, 
 int launch_scale_S_own(ba_problem *p, int64_t n, const double *d_dsc, double *d_S, const int64_t *d_col_off, const int *d_own_cols,
                        const int64_t *d_own_pref, int ncols, int64_t ntiles, hipStream_t st);
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
-                     hipStream_t st, const int *d_cam_pnt = nullptr);
+                     hipStream_t st, const int *d_cam_pnt = nullptr, const int *d_pos = nullptr /* block row of a camera */);
+int launch_gather_cams(ba_problem *p, const int *d_pos, const double *d_src, double *d_dst, hipStream_t st);
 int launch_backsub(ba_problem *p, const double *d_J, const double *d_Uinv, const double *d_u, const double *d_dc,
                    double *d_dp, hipStream_t st, const double *d_r_model = nullptr, double cr = 1.0, double *d_partial = nullptr,
                    double *d_scal = nullptr, int slot = 0, bool *model_done = nullptr);
@@ -122,7 +127,7 @@ int launch_sumsq_multi(ba_problem *p, SumsqJobs *jobs, double *d_partial_multi /
 int launch_axpy(ba_problem *p, int64_t n, const double *d_x, const double *d_d, double *d_y, hipStream_t st);
 int launch_hcc_diag(ba_problem *p, const double *d_Hcc, double *d_hdiag, hipStream_t st);
 int launch_cam_scale(ba_problem *p, const double *d_hdiag, double add, double *d_dsc, hipStream_t st,
-                     const double *d_lambda = nullptr);
+                     const double *d_lambda = nullptr, const int *d_pos = nullptr);
 int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, double *d_S, const int64_t *d_col_off,
                    hipStream_t st);
 int launch_scale_scalar(ba_problem *p, int64_t n, double *d_v, double alpha, hipStream_t st);

@@ -66,7 +66,9 @@ template <int MODE>
 __global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_ptr, const int *__restrict__ cam_obs,
                                                      const int *__restrict__ pnt0, const double *__restrict__ J,
                                                      const double *__restrict__ r, const double *__restrict__ u,
-                                                     double *__restrict__ Hcc, double *__restrict__ out9, double lam = 0.0) {
+                                                     double *__restrict__ Hcc, double *__restrict__ out9, double lam = 0.0,
+                                                     const int *__restrict__ opos = nullptr) {
+  // opos (MODE 2): the right-hand side of the camera system is written at the camera's block row of S (camera ordering)
   constexpr int NACC = (MODE == 0) ? 54 : 9;
   __shared__ double red[BLK / 64][NACC];
   const int c = blockIdx.x;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks(const int *__restrict__ cam_
       for (int j = 0; j < 9; j++) s += H[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * x[j];
       out9[9 * (int64_t)c + i] = (s + v) + lam * x[i];
     } else {
-      out9[9 * (int64_t)c + threadIdx.x] = v;
+      out9[9 * (int64_t)((MODE == 2 && opos) ? opos[c] : c) + threadIdx.x] = v;
     }
   }
 }
@@ -213,7 +215,8 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ c
                                                         const int *__restrict__ pnt0, const double *__restrict__ J,
                                                         const double *__restrict__ r, const double *__restrict__ u,
                                                         double *__restrict__ Hcc, double *__restrict__ out9, double lam = 0.0,
-                                                        const int *__restrict__ cam_pnt = nullptr) {
+                                                        const int *__restrict__ cam_pnt = nullptr,
+                                                        const int *__restrict__ opos = nullptr) {
   constexpr int NACC = (MODE == 0) ? 54 : 9;
   __shared__ double slots[(BLK / 64) * ST_WAVE_ELEMS];
   __shared__ double red[BLK / 64][NACC];
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(BLK) void k_cam_blocks_st(const int *__restrict__ c
       for (int j = 0; j < 9; j++) s += H[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * x[j];
       out9[9 * (int64_t)c + i] = (s + v) + lam * x[i];
     } else {
-      out9[9 * (int64_t)c + threadIdx.x] = v;
+      out9[9 * (int64_t)((MODE == 2 && opos) ? opos[c] : c) + threadIdx.x] = v;
     }
   }
 }
@@ -457,12 +460,15 @@ __device__ inline d4s schur_accumulate(int t_begin, int t_end, const int *__rest
 }
 
 // block (ca, cb) of S from the task sum `sum` (element (i, j) per lane as above; i >= 9 or fr >= 9: ignored)
+// ca, cb are block rows of S; cam_of (null: the identity) gives the camera that sits there (fill-reducing camera ordering)
 __device__ inline void schur_store_block(double *S, const int64_t *__restrict__ co, int ca, int cb, const double *__restrict__ Hcc,
-                                         double lambda, const double *__restrict__ damp_c, int i, int j, double sum) {
+                                         double lambda, const double *__restrict__ damp_c, int i, int j, double sum,
+                                         const int *__restrict__ cam_of) {
   double v = -sum;
   if (ca == cb) {
     int hi = i > j ? i : j, lo = i > j ? j : i;
-    v += Hcc[45 * (int64_t)ca + hi * (hi + 1) / 2 + lo] + (i == j ? (damp_c ? damp_c[9 * (int64_t)ca + i] : lambda) : 0.0);
+    const int64_t cam = cam_of ? cam_of[ca] : ca;
+    v += Hcc[45 * cam + hi * (hi + 1) / 2 + lo] + (i == j ? (damp_c ? damp_c[9 * cam + i] : lambda) : 0.0);
   }
   const int64_t r0 = 9 * (int64_t)ca, c0 = 9 * (int64_t)cb;
   if (r0 + i >= c0 + j) s_store(S, co, r0 + i, c0 + j, v);
@@ -476,7 +482,8 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
                                                        const double *__restrict__ Hcc, double lambda,
                                                        const double *__restrict__ lam_dev, double *__restrict__ S,
                                                        const int64_t *__restrict__ co, const double *__restrict__ damp_c,
-                                                       int split_above, const int *__restrict__ klist = nullptr) {
+                                                       int split_above, const int *__restrict__ klist = nullptr,
+                                                       const int *__restrict__ cam_of = nullptr) {
   // klist (per-rank ownership of S): the keys whose blocks touch the tile columns of the chunk being assembled; nkeys is
   // then the length of that list
   __shared__ double stage[BLK / 64][2][48];
@@ -499,7 +506,7 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const int i = fk + 4 * g;
-        if (i < 9) schur_store_block(S, co, ca, cb, Hcc, lambda, damp_c, i, fr, acc[g]);
+        if (i < 9) schur_store_block(S, co, ca, cb, Hcc, lambda, damp_c, i, fr, acc[g], cam_of);
       }
     }
   }
@@ -531,7 +538,8 @@ __global__ __launch_bounds__(BLK) void k_schur_combine(int64_t nsplit, const int
                                                         const double *__restrict__ partial, const double *__restrict__ Hcc,
                                                         double lambda, const double *__restrict__ lam_dev, double *__restrict__ S,
                                                         const int64_t *__restrict__ co, const double *__restrict__ damp_c,
-                                                        const int *__restrict__ slist = nullptr) {
+                                                        const int *__restrict__ slist = nullptr,
+                                                        const int *__restrict__ cam_of = nullptr) {
   if (lam_dev) lambda *= lam_dev[0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int64_t sq = (int64_t)blockIdx.x * (BLK / 64) + wv; sq < nsplit; sq += (int64_t)gridDim.x * (BLK / 64)) {
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(BLK) void k_schur_combine(int64_t nsplit, const int
     for (int e = lane; e < 81; e += 64) {
       double sum = 0;
       for (int c = c0; c < c1; c++) sum += partial[81 * (int64_t)c + e];
-      schur_store_block(S, co, ca, cb, Hcc, lambda, damp_c, e / 9, e % 9, sum);
+      schur_store_block(S, co, ca, cb, Hcc, lambda, damp_c, e / 9, e % 9, sum, cam_of);
     }
   }
 }
@@ -553,12 +561,15 @@ __global__ __launch_bounds__(BLK) void k_schur_combine(int64_t nsplit, const int
 // hdiag: diag(J'J) of the camera columns, summed over ALL ranks (k_hcc_diag + the gc all-reduce): the column norms are
 // those of the whole Jacobian, not of a rank's shard.
 __global__ __launch_bounds__(BLK) void k_cam_scale(int64_t ncams, const double *__restrict__ hdiag, double add,
-                                                    const double *__restrict__ lam_dev, double *__restrict__ dsc) {
+                                                    const double *__restrict__ lam_dev, double *__restrict__ dsc,
+                                                    const int *__restrict__ pos) {
   int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
   if (i >= 9 * ncams) return;
   if (lam_dev) add *= lam_dev[0];
   double v = sqrt(hdiag[i] + add);
-  dsc[i] = (v != 0.0) ? v : 1.0;  // col_norms[j] == 0 columns are left alone (lma_aux.jl:120,148)
+  // (pos: the block row of S a camera sits at under a fill-reducing camera ordering; dsc is indexed like S)
+  const int64_t o = pos ? 9 * (int64_t)pos[i / 9] + i % 9 : i;
+  dsc[o] = (v != 0.0) ? v : 1.0;  // col_norms[j] == 0 columns are left alone (lma_aux.jl:120,148)
 }
 
 // this rank's diag(Hcc) (packed lower 9x9 per camera) -> the 9*ncams vector that is all-reduced with gc
@@ -1242,7 +1253,7 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
     const double *damp_c = d_damp ? d_damp + 3 * p->npnts : (const double *)nullptr;
     hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nb), dim3(BLK), 0, st, T->nkeys, T->key_ptr,
                        T->key_ca, T->key_cb, T->task_a, T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, d_S, d_col_off, damp_c,
-                       T->nsplit > 0 ? 2 * T->chunk : 0);
+                       T->nsplit > 0 ? 2 * T->chunk : 0, (const int *)nullptr, T->cam_of);
     if (T->nsplit > 0) {  // long keys: chunk partials, then their fixed-order sums
       int64_t nbc = (T->nchunks + BLK / 64 - 1) / (BLK / 64), nbs = (T->nsplit + BLK / 64 - 1) / (BLK / 64);
       if (nbc > (int64_t)1 << 22) nbc = (int64_t)1 << 22;
@@ -1250,7 +1261,7 @@ int launch_schur_blocks(ba_problem *p, const SchurTasks *T, const double *d_J, c
       hipLaunchKernelGGL(k_schur_chunks, dim3((unsigned)nbc), dim3(BLK), 0, st, T->nchunks, T->chunk_t0, T->chunk_t1, T->task_a,
                          T->task_b, d_J, d_Y, T->partial);
       hipLaunchKernelGGL(k_schur_combine, dim3((unsigned)nbs), dim3(BLK), 0, st, T->nsplit, T->skey, T->skey_c0, T->key_ca,
-                         T->key_cb, T->partial, d_Hcc, lambda, d_lambda, d_S, d_col_off, damp_c);
+                         T->key_cb, T->partial, d_Hcc, lambda, d_lambda, d_S, d_col_off, damp_c, (const int *)nullptr, T->cam_of);
     }
   }
   if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, d_S, d_col_off);
@@ -1285,13 +1296,13 @@ int launch_schur_chunk(ba_problem *p, const SchurTasks *T, const SchurChunk *c, 
     int64_t nb = (c->nkeys + BLK / 64 - 1) / (BLK / 64);
     if (nb > (int64_t)1 << 22) nb = (int64_t)1 << 22;
     hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)nb), dim3(BLK), 0, st, c->nkeys, T->key_ptr, T->key_ca, T->key_cb, T->task_a,
-                       T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, dest, c->cco, damp_c, T->nsplit > 0 ? 2 * T->chunk : 0, c->keys);
+                       T->task_b, d_J, d_Y, d_Hcc, lambda, d_lambda, dest, c->cco, damp_c, T->nsplit > 0 ? 2 * T->chunk : 0, c->keys, T->cam_of);
   }
   if (c->nskeys > 0) {
     int64_t nbs = (c->nskeys + BLK / 64 - 1) / (BLK / 64);
     if (nbs > (int64_t)1 << 22) nbs = (int64_t)1 << 22;
     hipLaunchKernelGGL(k_schur_combine, dim3((unsigned)nbs), dim3(BLK), 0, st, c->nskeys, T->skey, T->skey_c0, T->key_ca, T->key_cb,
-                       T->partial, d_Hcc, lambda, d_lambda, dest, c->cco, damp_c, c->skeys);
+                       T->partial, d_Hcc, lambda, d_lambda, dest, c->cco, damp_c, c->skeys, T->cam_of);
   }
   if (npad > n) hipLaunchKernelGGL(k_pad_diag, dim3(grid_for(npad - n, BLK)), dim3(BLK), 0, st, n, npad, dest, c->cco);
   BA_HIP_CHECK(hipGetLastError());
@@ -1333,10 +1344,23 @@ int launch_hcc_diag(ba_problem *p, const double *d_Hcc, double *d_hdiag, hipStre
 }
 
 int launch_cam_scale(ba_problem *p, const double *d_hdiag, double add, double *d_dsc, hipStream_t st,
-                     const double *d_lambda) {
+                     const double *d_lambda, const int *d_pos) {
   if (p->ncams == 0) return BA_OK;
   hipLaunchKernelGGL(k_cam_scale, dim3(grid_for(9 * p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_hdiag, add, d_lambda,
-                     d_dsc);
+                     d_dsc, d_pos);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
+// dst[9 c + j] = src[9 pos[c] + j]: the camera part of the step back from the block rows of S to camera order
+__global__ __launch_bounds__(BLK) void k_gather_cams(int64_t ncams, const int *__restrict__ pos, const double *__restrict__ src,
+                                                      double *__restrict__ dst) {
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  if (i < 9 * ncams) dst[i] = src[9 * (int64_t)pos[i / 9] + i % 9];
+}
+int launch_gather_cams(ba_problem *p, const int *d_pos, const double *d_src, double *d_dst, hipStream_t st) {
+  if (p->ncams == 0) return BA_OK;
+  hipLaunchKernelGGL(k_gather_cams, dim3(grid_for(9 * p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_pos, d_src, d_dst);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }
@@ -1349,15 +1373,15 @@ int launch_scale_S(ba_problem *p, int64_t n, int64_t nt, const double *d_dsc, do
 }
 
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
-                     hipStream_t st, const int *d_cam_pnt) {
+                     hipStream_t st, const int *d_cam_pnt, const int *d_pos) {
   if (p->ncams == 0) return BA_OK;
   ProfScope ps(p, PC_SCHUR_RHS, st);
   if (staged_on())
     hipLaunchKernelGGL(k_cam_blocks_st<2>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
-                       d_r, d_u, (double *)nullptr, d_rhs, 0.0, d_cam_pnt);
+                       d_r, d_u, (double *)nullptr, d_rhs, 0.0, d_cam_pnt, d_pos);
   else
     hipLaunchKernelGGL(k_cam_blocks<2>, dim3((unsigned)p->ncams), dim3(BLK), 0, st, p->cam_ptr, p->cam_obs, p->pnt0, d_J,
-                       d_r, d_u, (double *)nullptr, d_rhs);
+                       d_r, d_u, (double *)nullptr, d_rhs, 0.0, d_pos);
   BA_HIP_CHECK(hipGetLastError());
   return BA_OK;
 }

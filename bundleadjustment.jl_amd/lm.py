@@ -18,7 +18,7 @@ from .model import BALNLPModel, FeasibilityResidual
 
 _FACTO = {"LDL": 0, "QR": 1, "PCG": 2}
 _NORM = {"None": 0, "J": 1, "A": 2}
-_PERM = ("AMD", "Metis")
+_PERM = ("AMD", "Metis", "natural")
 
 
 @dataclass
@@ -60,7 +60,7 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
     if facto not in _FACTO:
         raise ValueError(f"facto must be :QR, :LDL or :PCG (extension: matrix-free CG on the reduced camera system), got {facto!r}")
     if perm not in _PERM:
-        raise ValueError(f"perm must be :AMD or :Metis, got {perm!r}")
+        raise ValueError(f"perm must be :AMD or :Metis (or :natural, an extension: the caller's camera numbering), got {perm!r}")
     if normalize not in _NORM:
         raise ValueError(f"normalize must be :None, :J or :A, got {normalize!r}")
     nlp = model.nlp if isinstance(model, FeasibilityResidual) else model
@@ -94,7 +94,8 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
                     facto_type=ft, ite_max=-1 if ite_max is None else int(ite_max), verbose=int(verbose), x_f32=int(xf32),
                     restol=d(restol), satol=d(satol), srtol=d(srtol), oatol=d(oatol), ortol=d(ortol), atol=d(atol),
                     rtol=d(rtol), nu_d=d(nu_d), nu_m=d(nu_m), lam=d(lam), delta_d=d(delta_d), max_time=d(max_time),
-                    pcg_tol=d(pcg_tol), pcg_max_iter=-1 if pcg_max_iter is None else int(pcg_max_iter))
+                    pcg_tol=d(pcg_tol), pcg_max_iter=-1 if pcg_max_iter is None else int(pcg_max_iter),
+                    perm=_lib.ORDERINGS[perm])  # src/lm.jl:84-88: orders the cameras of the reduced system (ba_order.cpp)
     st = _lib.LMStats()
     rows = []
 
@@ -144,6 +145,20 @@ def schur_pattern(nlp):
     tf, ff, sp = C.c_double(0), C.c_double(0), C.c_int(0)
     _lib.check(_lib.lib().ba_lm_schur_pattern(nlp.handle, C.byref(tf), C.byref(ff), C.byref(sp)))
     return tf.value, ff.value, bool(sp.value)
+
+
+def set_ordering(nlp, perm):
+    """Camera ordering of the handle's next direct solves outside Levenberg_Marquardt (lm_step): "AMD", "Metis", "natural"."""
+    _lib.check(_lib.lib().ba_lm_set_ordering(nlp.handle, _lib.ORDERINGS[_sym(perm)]))
+
+
+def schur_ordering_used(nlp):
+    """(perm1, name): the camera sequence of the reduced camera system of a handle that has run a direct solve (perm1[k] =
+    1-based camera at block row k of S) and the name of the candidate sequence that won (ba_lm_schur_ordering)."""
+    perm = np.zeros(nlp.ncams, dtype=np.int64)
+    name = C.c_char_p()
+    _lib.check(_lib.lib().ba_lm_schur_ordering(nlp.handle, _lib.ptr(perm), C.byref(name)))
+    return perm, name.value.decode()
 
 
 def schur_memory(nlp):

@@ -117,6 +117,40 @@ def make_problem(ncams, npnts, nobs, seed=BASE_SEED, locality=None):
                 ncams=int(ncams), npnts=int(npnts), nobs=int(nobs))
 
 
+def shuffle_cameras(prob, seed=0, sigma=None):
+    """The same problem with its cameras renumbered at random: (problem, sigma) with camera c of `prob` called sigma[c]
+    (0-based) in the result; observations stay in BAL order (by point, then by the NEW camera number).  A BAL file promises
+    nothing about how its cameras are numbered: this is what a fill-reducing ordering (`perm`, src/lm.jl:84-88) has to undo.
+    Camera blocks of x map as x_new[3 npnts + 9 sigma[c] + j] = x[3 npnts + 9 c + j]; points keep their numbers.
+    sigma: an explicit renumbering instead of a random one."""
+    ncams, npnts, nobs = prob["ncams"], prob["npnts"], prob["nobs"]
+    sigma = (np.random.default_rng(seed).permutation(ncams) if sigma is None else np.asarray(sigma)).astype(np.int64)
+    assert sorted(sigma.tolist()) == list(range(ncams))
+    cam0 = sigma[np.asarray(prob["cam_idx1"]) - 1]
+    pnt0 = np.asarray(prob["pnt_idx1"]) - 1
+    order = np.lexsort((cam0, pnt0))
+    out = dict(prob)
+    out["cam_idx1"] = cam0[order] + 1
+    out["pnt_idx1"] = pnt0[order] + 1
+    out["pt2d"] = np.ascontiguousarray(np.asarray(prob["pt2d"]).reshape(nobs, 2)[order].ravel())
+    for key in ("x0", "x_true"):
+        x = np.array(prob[key], copy=True)
+        cams = x[3 * npnts:].reshape(ncams, 9)
+        new = np.empty_like(cams)
+        new[sigma] = cams
+        x[3 * npnts:] = new.ravel()
+        out[key] = x
+    return out, sigma
+
+
+def unshuffle_vector(v, sigma, npnts):
+    """A vector in the layout of x of a shuffle_cameras problem, back in the original camera numbering."""
+    v = np.array(v, copy=True)
+    cams = v[3 * npnts:].reshape(len(sigma), 9)
+    v[3 * npnts:] = cams[sigma].ravel()
+    return v
+
+
 def schur_fill(prob, tile=128):
     """(block fill, tile fill) of the reduced camera matrix of a problem: the fraction of camera pairs (a >= b) that share at
     least one point, and the fraction of the lower tile x tile tiles of S (rows / columns 9 * camera) that hold such a pair

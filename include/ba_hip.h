@@ -118,8 +118,9 @@ int ba_synchronize(ba_problem *p);
  * The linear step (J'J + lambda I) delta = -J' r -- which the reference obtains from a sparse LDL^T
  * (or QR) of the augmented system, src/lm.jl:154-238 -- is solved on the device through the
  * point-eliminated (Schur) reduced camera system and a dense blocked LDL^T on the f64 matrix cores;
- * `facto` and `perm` therefore only select behaviour that survives that change (both :QR and :LDL
- * give the same step; the fill-reducing ordering has no counterpart).  Negative tolerances / zero
+ * `facto` and `perm` therefore only select behaviour that survives that change: both :QR and :LDL
+ * give the same step; `perm` orders what is left to order, the cameras of the reduced system (its
+ * residual rows and points are eliminated first, as AMD orders them).  Negative tolerances / zero
  * parameters mean "the variant's default" (eps-derived, src/lm.jl:20-26 and
  * src/LevenbergMarquardt.jl:21-26). */
 typedef struct ba_lm_opts {
@@ -148,7 +149,9 @@ typedef struct ba_lm_opts {
   double max_time;                                        /* <=0: 3600 (inert in the reference, lm.jl:33,115,382) */
   double pcg_tol;                                         /* facto = 2: relative residual of the CG solve, <=0: 1e-8 */
   int pcg_max_iter;                                       /* facto = 2: CG iterations per LM step, <=0: 1000 */
-  int reserved1;
+  int perm;       /* fill-reducing ordering (src/lm.jl:84-88, src/LevenbergMarquardt.jl:106-110): 0 :AMD, 1 :Metis,
+                   *    2 the caller's camera numbering.  Applied to the cameras of the reduced camera system
+                   *    (ba_schur_ordering); x, J and every vector at this boundary keep the caller's numbering */
 } ba_lm_opts;
 
 typedef struct ba_lm_stats {
@@ -227,6 +230,27 @@ int ba_lm_step_pcg(ba_problem *p, const double *x, double lambda, double tol, in
  * (one GPU; BA_SPARSE_S=1 / 0 forces it on / off).  tile_fill: pattern tiles (with fill) / all lower tiles; flop_fill: trailing-update tiles of the pattern / of the
  * dense factorisation; sparse_schedule: 1 when the list schedule is in use.  Valid after the first direct solve. */
 int ba_lm_schur_pattern(ba_problem *p, double *tile_fill, double *flop_fill, int *sparse_schedule);
+
+/* ---- fill-reducing camera ordering: `perm` = :AMD / :Metis, src/lm.jl:84-88, consumed by ldl_analyse,
+ * src/ldl_aux.jl:246-283 ---------------------------------------------------------------------------------
+ * The reference orders the augmented matrix K with AMD.jl or Metis.jl (third-party C libraries, absent here).  On the
+ * device the residual rows and the points are eliminated first, in closed form; what remains to be ordered is the camera
+ * graph (cameras adjacent when they share a point), and an ordering is judged by the 128 x 128 TILE pattern it leaves.
+ * method 0 (:AMD): minimum degree with an elimination-tree postorder; 1 (:Metis): nested dissection by level-structure
+ * separators; both also offer reverse Cuthill-McKee sequences (hub cameras deferred) and the caller's numbering, and keep
+ * the sequence whose symbolic factorisation is cheapest; 2: the caller's numbering.  Only the reduced camera system is
+ * permuted (inside the handle); every array at this boundary keeps the caller's camera numbering.
+ *   ba_schur_ordering    : host only, no device: the ordering of a problem and the fill it leaves.  perm1 (ncams, may be
+ *                          NULL): perm1[k] = the 1-based camera at block row k of S; tile_fill / flop_fill as
+ *                          ba_lm_schur_pattern; block_fill: camera pairs sharing a point / all pairs.
+ *   ba_lm_set_ordering   : ordering of the handle's next direct solves (default 0; ba_lm_solve sets it from opts.perm).
+ *                          Changing it after a direct solve drops the handle's reduced-system workspace.
+ *   ba_lm_schur_ordering : the sequence in use after the first direct solve, and the name of the candidate that won
+ *                          (static storage). */
+int ba_schur_ordering(int64_t ncams, int64_t npnts, int64_t nobs, const int64_t *cam_idx1, const int64_t *pnt_idx1,
+                      int method, int64_t *perm1, double *tile_fill, double *flop_fill, double *block_fill);
+int ba_lm_set_ordering(ba_problem *p, int method);
+int ba_lm_schur_ordering(ba_problem *p, int64_t *perm1, const char **name);
 /* What a handle holds of the reduced camera matrix, in 128 x 128 tiles of its scalar type (Float64; a Float32 factorisation
  * adds half of that again): tiles_full = the whole lower triangle, nt (nt + 1) / 2; tiles_held = what this handle allocated
  * for S; tiles_staging = the staging buffer of the chunked assembly.  One GPU (and BA_DIST_FACTOR=0): held = full,

@@ -54,7 +54,7 @@ struct BaLmOpts
   max_time :: Cdouble
   pcg_tol :: Cdouble
   pcg_max_iter :: Cint
-  reserved1 :: Cint
+  perm :: Cint
 end
 
 # struct ba_lm_stats (include/ba_hip.h)

@@ -23,7 +23,7 @@ function _ba_lm(model, variant :: Int, facto :: Symbol, perm :: Symbol, normaliz
   facto in (:QR, :LDL, :PCG) || error("facto must be :QR, :LDL or :PCG")
   (facto == :PCG && normalize != :None) && error("facto = :PCG has its own scaling (block-Jacobi preconditioner): normalize must be :None")
   (facto == :PCG && facto_type == Float32 && T != Float32) && error("facto = :PCG runs in Float64: facto_type = Float32 belongs to the direct branches")
-  perm in (:AMD, :Metis) || error("perm must be :AMD or :Metis")   # kept for the signature: the device elimination order is fixed
+  perm in (:AMD, :Metis) || error("perm must be :AMD or :Metis")   # src/lm.jl:84-88: orders the cameras of the reduced system (ba_lm_opts.perm)
   normalize in (:None, :J, :A) || error("normalize must be :None, :J or :A")
   nlp = model.nlp                       # the BALNLPModel inside FeasibilityResidual (src/solve_ba.jl:25)
   T = eltype(x)
@@ -33,7 +33,7 @@ function _ba_lm(model, variant :: Int, facto :: Symbol, perm :: Symbol, normaliz
   o = BaLmOpts(variant, facto == :QR ? 1 : facto == :PCG ? 2 : 0, normalize == :None ? 0 : normalize == :J ? 1 : 2, linesearch ? 1 : 0, ft,
                ite_max, 0, T == Float32 ? 1 : 0, _tol(restol), _tol(satol), _tol(srtol), _tol(oatol), _tol(ortol),
                _tol(atol), _tol(rtol), _tol(νd), _tol(νm), _tol(λ), _tol(δd), Float64(max_time), Float64(pcg_tol),
-               Cint(pcg_max_iter), Cint(0))
+               Cint(pcg_max_iter), Cint(perm == :Metis ? 1 : 0))
   st = BaLmStats()
   xd = Vector{Float64}(x)               # the ABI carries the iterate as doubles (exact for Float32 values)
   cb = @cfunction(_ba_log_row, Cvoid, (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint))

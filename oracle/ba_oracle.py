@@ -82,6 +82,9 @@ def lib():
     L.orc_lm_step.argtypes = [C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f64p, f64p, C.c_double, f64p,
                               C.c_void_p, C.c_void_p]
     L.orc_lm_step.restype = C.c_int
+    L.orc_lm_step_perm.argtypes = [C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f64p, f64p, C.c_double, C.c_void_p, f64p,
+                                   C.c_void_p, C.c_void_p]
+    L.orc_lm_step_perm.restype = C.c_int
     L.orc_qr_lstsq.argtypes = [C.c_int64, C.c_int64, f64p, f64p]
     L.orc_qr_lstsq.restype = C.c_int
     _LIB = L
@@ -177,14 +180,17 @@ def qr_lstsq(A, b):
     return rc, bb[:n]
 
 
-def lm_step(ncams, npnts, cam_idx1, pnt_idx1, pt2d, x, lam):
+def lm_step(ncams, npnts, cam_idx1, pnt_idx1, pt2d, x, lam, cam_perm1=None):
+    """cam_perm1: the cameras' elimination order handed to ldl_analyse (src/ldl_aux.jl:246-283); None: the identity."""
     nobs = len(cam_idx1)
     nvar = 9 * ncams + 3 * npnts
     delta = np.zeros(nvar)
     dr = np.zeros(2 * nobs)
     jtr = np.zeros(nvar)
-    rc = lib().orc_lm_step(ncams, npnts, nobs, _i64(cam_idx1), _i64(pnt_idx1), _f64(pt2d), _f64(x), float(lam),
-                           delta, dr.ctypes.data_as(C.c_void_p), jtr.ctypes.data_as(C.c_void_p))
+    perm = None if cam_perm1 is None else _i64(cam_perm1)
+    rc = lib().orc_lm_step_perm(ncams, npnts, nobs, _i64(cam_idx1), _i64(pnt_idx1), _f64(pt2d), _f64(x), float(lam),
+                                perm.ctypes.data_as(C.c_void_p) if perm is not None else None,
+                                delta, dr.ctypes.data_as(C.c_void_p), jtr.ctypes.data_as(C.c_void_p))
     return rc, delta, dr, jtr
 
 

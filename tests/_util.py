@@ -1,8 +1,34 @@
 """Small helpers shared by the GPU tests: self-describing comparisons (a failure names the field, the count and the place
 of the differences -- never a dump of the arrays)."""
 import hashlib
+import json
+import os
 
 import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARITY_REPORT = os.path.join(_ROOT, "gpurun_out", "parity_report.json")
+_parity = {}
+
+
+def parity_record(test, **values):
+    """Record what a parity test ACHIEVED (max errors, fills, counts) under its name and rewrite
+    gpurun_out/parity_report.json -- the numbers behind the asserts, kept with the run (a summary is committed under
+    profiles/).  Values: floats / ints / strings."""
+    entry = _parity.setdefault(test, {})
+    for k, v in values.items():
+        entry[k] = v if isinstance(v, (str, bool)) else (int(v) if isinstance(v, (int, np.integer)) else float(v))
+    try:
+        os.makedirs(os.path.dirname(PARITY_REPORT), exist_ok=True)
+        old = {}
+        if os.path.exists(PARITY_REPORT):
+            with open(PARITY_REPORT) as fh:
+                old = json.load(fh)
+        old.update(_parity)
+        with open(PARITY_REPORT, "w") as fh:
+            json.dump(old, fh, indent=1, sort_keys=True)
+    except (OSError, ValueError):
+        pass  # the report is a by-product: never the reason a parity test fails
 
 
 def digest(a):

@@ -20,7 +20,7 @@ int main(int argc, char **argv) {
   OFF(ba_lm_opts, facto_type); OFF(ba_lm_opts, ite_max); OFF(ba_lm_opts, verbose); OFF(ba_lm_opts, x_f32);
   OFF(ba_lm_opts, restol); OFF(ba_lm_opts, satol); OFF(ba_lm_opts, srtol); OFF(ba_lm_opts, oatol);
   OFF(ba_lm_opts, ortol); OFF(ba_lm_opts, atol); OFF(ba_lm_opts, rtol); OFF(ba_lm_opts, nu_d); OFF(ba_lm_opts, nu_m);
-  OFF(ba_lm_opts, lambda); OFF(ba_lm_opts, delta_d); OFF(ba_lm_opts, max_time); OFF(ba_lm_opts, pcg_tol); OFF(ba_lm_opts, pcg_max_iter); OFF(ba_lm_opts, reserved1);
+  OFF(ba_lm_opts, lambda); OFF(ba_lm_opts, delta_d); OFF(ba_lm_opts, max_time); OFF(ba_lm_opts, pcg_tol); OFF(ba_lm_opts, pcg_max_iter); OFF(ba_lm_opts, perm);
   printf("sizeof ba_lm_stats %zu\n", sizeof(ba_lm_stats));
   OFF(ba_lm_stats, status); OFF(ba_lm_stats, iter); OFF(ba_lm_stats, n_accepted); OFF(ba_lm_stats, n_rejected);
   OFF(ba_lm_stats, n_residual); OFF(ba_lm_stats, n_jacobian); OFF(ba_lm_stats, n_factor); OFF(ba_lm_stats, n_cg);

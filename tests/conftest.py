@@ -19,7 +19,7 @@ def pytest_configure(config):
 # Collection order: the oracle-parity tests first, then the single-process determinism / loopback tests, the
 # multi-process (torchrun) tests last -- `pytest -x` must never again stop in a multi-process test before the parity
 # suite has run (round 2's driver run did: tests/test_distributed.py sorts before tests/test_gpu_parity.py).
-_ORDER = ["test_oracle_golden.py", "test_host.py", "test_gpu_parity.py", "test_gpu_determinism.py", "test_distributed.py"]
+_ORDER = ["test_oracle_golden.py", "test_host.py", "test_ordering.py", "test_gpu_parity.py", "test_gpu_determinism.py", "test_distributed.py"]
 
 
 def pytest_collection_modifyitems(session, config, items):

@@ -12,9 +12,13 @@ Tolerances (stated, fp64):
   * LM run: identical accept/reject sequence and iteration count on the small shapes, final objective <= 1e-8 relative.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _util import parity_record as _report  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 EPS = 2.220446049250313e-16
@@ -1082,3 +1086,150 @@ def test_block_sparse_factor_time_follows_the_pattern(ba, gpu_ok):
     assert pat[2] and pat[1] <= 0.6
     assert ms_s < 0.95 * ms_d, f"list schedule {ms_s:.2f} ms, dense schedule {ms_d:.2f} ms (best of three each)"
     assert np.linalg.norm(d_s - d_d) <= 1e-10 * np.linalg.norm(d_d)
+
+
+# ---- fill-reducing camera ordering: `perm` = :AMD / :Metis (src/lm.jl:84-88, src/LevenbergMarquardt.jl:106-110, consumed by
+# ---- ldl_analyse, src/ldl_aux.jl:246-283).  AMD.jl / Metis.jl are third-party C libraries absent from the image: the
+# ---- sequences themselves are parity unpinned; what is pinned is that the step does not depend on them ---------------------
+@pytest.mark.parametrize("method", ["AMD", "Metis"])
+def test_camera_ordering_on_a_randomly_numbered_problem(ba, orc, gpu_ok, method):
+    """A block-banded problem (locality 0.13) whose cameras are renumbered at random: in the caller's numbering every tile of
+    S is occupied and the factorisation is dense.  With `perm` the cameras are ordered inside the handle: tile fill within
+    1.25 x of the well-numbered problem's, the list schedule chosen by itself, the step equal to the oracle's (whose
+    ldl_analyse gets the same camera sequence as its permutation) to 1e-9 and to the well-numbered problem's step, mapped back,
+    to 1e-10.  Every vector at the boundary stays in the caller's numbering."""
+    p = ba.synthetic.make_problem(600, 6000, 30000, seed=23, locality=0.13)  # n = 5400: 43 tile rows
+    q, sigma = ba.synthetic.shuffle_cameras(p, seed=1)
+    lam = 5.0
+
+    def run(prob, order):
+        m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob))
+        ba.set_ordering(m, order)
+        d, half, jtr = ba.lm_step(m, prob["x0"], lam)
+        pat = ba.schur_pattern(m)
+        perm, name = ba.schur_ordering_used(m)
+        m.close()
+        return d, half, jtr, pat, perm, name
+
+    d0, half0, jtr0, pat0, perm0, name0 = run(p, "natural")
+    dn, halfn, _, patn, permn, _ = run(q, "natural")
+    d1, half1, jtr1, pat1, perm1, name1 = run(q, method)
+    print(f"{method}: tile fill {pat0[0]:.3f} as generated, {patn[0]:.3f} renumbered at random, {pat1[0]:.3f} with the ordering "
+          f"('{name1}'); update tiles / dense {pat0[1]:.4f} / {patn[1]:.4f} / {pat1[1]:.4f}")
+    assert np.array_equal(perm0, np.arange(1, 601)) and np.array_equal(permn, np.arange(1, 601))
+    assert sorted(perm1.tolist()) == list(range(1, 601)) and name1 != "natural"
+    assert patn[0] > 0.95 and not patn[2], "a random numbering fills S: dense schedule"
+    assert pat1[0] <= 1.25 * pat0[0], (pat1, pat0)
+    assert pat0[2] and pat1[2], "list schedule chosen automatically"
+    # the host-only entry gives the same sequence and fill
+    perm_h, tf_h, ff_h, _ = ba.schur_ordering(q["cam_idx1"], q["pnt_idx1"], q["ncams"], q["npnts"], method)
+    assert np.array_equal(perm_h, perm1) and abs(tf_h - pat1[0]) < 1e-12 and abs(ff_h - pat1[1]) < 1e-12
+    rc, d_ref, dr_ref, jtr_ref = orc.lm_step(q["ncams"], q["npnts"], q["cam_idx1"], q["pnt_idx1"], q["pt2d"], q["x0"], lam, cam_perm1=perm1)
+    assert rc == 0
+    e_orc = np.linalg.norm(d1 - d_ref) / np.linalg.norm(d_ref)
+    e_back = np.linalg.norm(ba.synthetic.unshuffle_vector(d1, sigma, p["npnts"]) - d0) / np.linalg.norm(d0)
+    e_dense = np.linalg.norm(d1 - dn) / np.linalg.norm(dn)
+    _report("camera_ordering_" + method, step_vs_oracle=e_orc, step_vs_well_numbered=e_back, step_vs_dense_schedule=e_dense,
+            tile_fill=pat1[0], tile_fill_well_numbered=pat0[0], sequence=name1)
+    assert e_orc <= 1e-9, f"ordered step vs oracle: {e_orc:.3e}"
+    assert e_back <= 1e-10, f"ordered step vs the well-numbered problem's: {e_back:.3e}"
+    assert e_dense <= 1e-10, f"ordered (list schedule) vs unordered (dense schedule) on the same problem: {e_dense:.3e}"
+    assert abs(half1 - 0.5 * float(dr_ref @ dr_ref)) <= 1e-10 * half1
+    assert np.max(np.abs(jtr1 - jtr_ref)) <= 1e-10 * np.max(np.abs(jtr_ref))  # J'r stays in the caller's numbering
+
+
+def test_camera_ordering_through_levenberg_marquardt(ba, orc, gpu_ok):
+    """`perm` reaches the device through Levenberg_Marquardt (ba_lm_opts.perm): complete lm.jl runs on a randomly numbered
+    problem with :AMD, :Metis and with the caller's numbering agree with the oracle's run (iterations, status, rows), with
+    :J scaling too (the column scaling lives in the order of S)."""
+    p = ba.synthetic.make_problem(320, 2400, 12000, seed=24, locality=0.12)  # n = 2880: 23 tile rows
+    q, _ = ba.synthetic.shuffle_cameras(p, seed=2)
+    rc, x_ref, st_ref, log_ref = orc.lm_solve(q["ncams"], q["npnts"], q["cam_idx1"], q["pnt_idx1"], q["pt2d"], q["x0"], variant=1, ite_max=6)
+    assert rc == 0
+    n = _well_conditioned_prefix(log_ref)
+    seen = {}
+    for perm, norm in (("AMD", "None"), ("Metis", "None"), ("natural", "None"), ("AMD", "J")):
+        m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(q))
+        st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "LDL", perm, norm, False, ite_max=6)
+        pat, used = ba.schur_pattern(m), ba.schur_ordering_used(m)
+        m.close()
+        print(perm, norm, st.status, st.iter, st.objective, pat, used[1])
+        seen[(perm, norm)] = (st, pat, used)
+        assert st.iter == st_ref.iter and st.status == orc.STATUS[st_ref.status]
+        if norm == "None":
+            _compare_rows(st, log_ref, n)
+        assert abs(st.objective - st_ref.objective) <= 1e-8 * st_ref.objective
+    assert seen[("AMD", "None")][1][2] and seen[("Metis", "None")][1][2] and not seen[("natural", "None")][1][2]
+    assert seen[("natural", "None")][2][1] == "natural"
+
+
+def _irregular_problem(ba, ncams, npnts, nobs, seed, group=14):
+    """A block-banded problem whose cameras are renumbered in whole groups of `group` (one tile's worth): in the caller's
+    numbering the tile pattern is neither full nor a band -- row lists with gaps, tile column pairs that differ."""
+    p = ba.synthetic.make_problem(ncams, npnts, nobs, seed=seed, locality=0.14)
+    ng = ncams // group
+    gperm = np.random.default_rng(seed).permutation(ng)
+    sigma = np.arange(ncams)
+    for g in range(ng):
+        sigma[g * group:(g + 1) * group] = gperm[g] * group + np.arange(group)
+    return ba.synthetic.shuffle_cameras(p, sigma=sigma)[0]
+
+
+@pytest.mark.parametrize("ncams", [156, 310])
+def test_block_sparse_irregular_pattern(ba, orc, gpu_ok, ncams):
+    """Irregular tile pattern, odd number of tile rows (156 cameras: n = 1404, 11 tile rows; 310: n = 2790, 22 ... the last
+    tile column pair single or full), caller's numbering kept: the list schedule over row lists with gaps and compressed
+    storage against the dense schedule and the oracle, Float64 and Float32, row-split and big update kernels."""
+    q = _irregular_problem(ba, ncams, 10 * ncams, 50 * ncams, seed=40 + ncams)
+    lam = 3.0
+    rc, d_ref, dr_ref, _ = orc.lm_step(q["ncams"], q["npnts"], q["cam_idx1"], q["pnt_idx1"], q["pt2d"], q["x0"], lam)
+    assert rc == 0
+
+    def run(facto_type=None):
+        m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(q))
+        ba.set_ordering(m, "natural")
+        d, half, _ = ba.lm_step(m, q["x0"], lam, facto_type=facto_type)
+        pat, mem = ba.schur_pattern(m), ba.schur_memory(m)
+        m.close()
+        return d, pat, mem
+
+    d_s, pat_s, mem_s = _with_env("BA_SPARSE_S", "1", run)
+    d_d, pat_d, mem_d = _with_env("BA_SPARSE_S", "0", run)
+    d_big, _, _ = _with_env("BA_LDL_UPDATE_RS_MAX", "0", lambda: _with_env("BA_SPARSE_S", "1", run))
+    d32_s, _, _ = _with_env("BA_SPARSE_S", "1", lambda: run(np.float32))
+    d32_d, _, _ = _with_env("BA_SPARSE_S", "0", lambda: run(np.float32))
+    nt = (9 * ncams + 127) // 128
+    print(f"{ncams} cameras, {nt} tile rows: tile fill {pat_s[0]:.3f}, update tiles / dense {pat_s[1]:.3f}, tiles held {mem_s[1]} of {mem_s[0]}")
+    assert pat_s[2] and not pat_d[2] and 0.2 < pat_s[0] < 0.95, "the pattern should be irregular, not full"
+    assert mem_s[1] < mem_d[1] == mem_s[0] == nt * (nt + 1) // 2
+    e = {"sparse_vs_oracle": np.linalg.norm(d_s - d_ref) / np.linalg.norm(d_ref),
+         "sparse_vs_dense": np.linalg.norm(d_s - d_d) / np.linalg.norm(d_d),
+         "big_kernel_vs_row_split": np.linalg.norm(d_big - d_s) / np.linalg.norm(d_s),
+         "f32_sparse_vs_oracle": np.linalg.norm(d32_s - d_ref) / np.linalg.norm(d_ref),
+         "f32_sparse_vs_f32_dense": np.linalg.norm(d32_s - d32_d) / np.linalg.norm(d32_d)}
+    _report(f"block_sparse_irregular_{ncams}", **e)
+    assert e["sparse_vs_oracle"] <= 1e-9 and e["sparse_vs_dense"] <= 1e-11 and e["big_kernel_vs_row_split"] <= 1e-11, e
+    assert e["f32_sparse_vs_oracle"] <= 5e-3 and e["f32_sparse_vs_f32_dense"] <= 1e-4, e
+
+
+@pytest.mark.parametrize("ncams", [10, 20, 40])
+def test_block_sparse_forced_on_tiny_systems(ba, orc, gpu_ok, ncams):
+    """One, two and three tile rows with the list schedule forced on (BA_SPARSE_S=1): the degenerate ends of every list."""
+    p = ba.synthetic.make_problem(ncams, 40 * ncams, 160 * ncams, seed=50 + ncams)
+    rc, d_ref, _, _ = orc.lm_step(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"], 2.0)
+    assert rc == 0
+
+    def run(facto_type=None):
+        m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+        d, _, _ = ba.lm_step(m, p["x0"], 2.0, facto_type=facto_type)
+        pat = ba.schur_pattern(m)
+        m.close()
+        return d, pat
+
+    d_s, pat = _with_env("BA_SPARSE_S", "1", run)
+    d32, _ = _with_env("BA_SPARSE_S", "1", lambda: run(np.float32))
+    assert pat[2]
+    e = np.linalg.norm(d_s - d_ref) / np.linalg.norm(d_ref)
+    e32 = np.linalg.norm(d32 - d_ref) / np.linalg.norm(d_ref)
+    _report(f"block_sparse_tiny_{ncams}", step_vs_oracle=e, f32_step_vs_oracle=e32)
+    assert e <= 1e-9 and e32 <= 5e-3, (e, e32)
