@@ -29,20 +29,52 @@ MFMA_F32_PEAK_TF = 157.3   # FP32 matrix peak (v_mfma_f32_16x16x4_f32: twice the
 MFMA_F64_PEAK_TF = 78.6    # MI355X FP64 matrix peak (vendor sheet; v_mfma_f64_16x16x4_f64, 2048 flop / 64 clk / SIMD)
 
 
+def kernel_sources_sha():
+    """sha256 over the device sources (csrc/*.hip, csrc/*.h, csrc/*.cpp, in name order): what a PMC measurement is a
+    measurement OF.  tools/pmc_traffic.py stamps the file it writes with it."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "bundleadjustment.jl_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this workload (profiles/pmc_traffic_<workload>.json,
     written by tools/collect_pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this very command; the
-    counters cannot be read from inside the timed process).  None when no such measurement is committed."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{workload}.json")
+    counters cannot be read from inside the timed process).  None when no such measurement is committed -- or when it was
+    taken on other kernel sources than the ones this run was built from (the file carries their sha256): a stale number is
+    not reported."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"]
+            d = json.load(f)
+        k = d["kernels"]
     except (OSError, ValueError, KeyError):
+        return None
+    if d.get("kernel_sources_sha256") != kernel_sources_sha():
         return None
     for name, v in k.items():
         if name.startswith(kernel):
             return v["hbm_bytes_per_launch"]
     return None
+
+
+def pmc_stamp(workload):
+    """what the bench line says about where `traffic` comes from"""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return {"file": None}
+    now = kernel_sources_sha()
+    return {"file": os.path.relpath(path, ROOT), "taken_at_commit": d.get("commit"), "kernel_sources_sha256": (d.get("kernel_sources_sha256") or "")[:16],
+            "current_sources_sha256": now[:16], "current": d.get("kernel_sources_sha256") == now}
 
 
 def parse():
@@ -377,6 +409,7 @@ def main():
                    "n_jacobian": st.n_jacobian, "n_factor": st.n_factor, "n_cg": st.n_cg, "loop_s": st.loop_time},
             "pcg": pcg_line,
             "roofline": roof,
+            "roofline_traffic_source": pmc_stamp(args.workload),
             "roofline_jacobian": roof_jac,
             "roofline_residual": roof_res,
             "cpu_baseline": cpu,

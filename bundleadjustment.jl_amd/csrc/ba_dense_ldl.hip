@@ -721,68 +721,6 @@ __device__ inline void tile_gemm_abt_priv(const T *__restrict__ A0, const T *__r
   }
 }
 
-// LDS-DMA variant of the wave-private product (Float64): the operand chunks go global -> LDS directly
-// (global_load_lds_dwordx4: no staging VGPRs, no ds_write, no wait between a load and its LDS write), chunks of 8, two LDS
-// buffers per wave (16 KB per wave, 64 KB per workgroup); the next chunk's 8 pieces are in flight during the MFMAs and the
-// wave waits with vmcnt only.  A piece lands at base + lane * 16 bytes, so rows are unpadded (64 B): the 16-byte columns are
-// XOR-swizzled with the row ((row >> 2) & 3), which keeps the MFMA operand reads at two dwords per bank.  Same products in
-// the same order as tile_gemm_abt_priv (bit-identical accumulators; tools/bench_mfma_probe.py modes 3 / 5 compare their
-// checksums).  Probe, nonzero operands, steady state: 68.6-68.7 TFLOP/s against 66.1-66.2 for the register-staged loop.
-constexpr int DKC = 8;
-constexpr size_t GEMM_DMA_LDS_ELEMS = (size_t)4 * 2 * 2 * 64 * DKC;
-__device__ inline void tile_gemm_abt_dma(const double *__restrict__ A0, const double *__restrict__ B0,
-                                         const double *__restrict__ A1, const double *__restrict__ B1, double *lds,
-                                         RT<double>::v4 acc[4][4]) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
-  const int fr = lane & 15, fk = lane >> 4;
-  double *wbase = lds + wv * (2 * 2 * 64 * DKC);  // [buffer][A | B][64 rows][8]
-  const int prow = lane >> 2, pc2 = lane & 3;     // a piece: 16 rows x 64 B; this lane's row and 16-byte slot inside it
-  int off[2][4];  // operand read offsets inside a 64 x 8 slice: row r, element k -> r*8 + (((k>>1) ^ ((r>>2)&3)) << 1) + (k&1)
-#pragma unroll
-  for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      const int r = 16 * m + fr, k = 4 * kk + fk;
-      off[kk][m] = r * DKC + (((k >> 1) ^ ((r >> 2) & 3)) << 1) + (k & 1);
-    }
-  constexpr int NCHK = 2 * NB / DKC, HALF = NB / DKC;
-  auto issue = [&](int ch) {  // 8 DMA pieces: chunk ch of A and B into buffer ch & 1
-    double *dst = wbase + (ch & 1) * (2 * 64 * DKC);
-    const double *A = (ch < HALF ? A0 : A1) + (size_t)wr * NB, *B = (ch < HALF ? B0 : B1) + (size_t)wc * NB;
-    const int k0 = (ch & (HALF - 1)) * DKC;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r = 16 * q + prow;
-      const int c2 = pc2 ^ ((r >> 2) & 3);
-      __builtin_amdgcn_global_load_lds(A + (size_t)r * NB + k0 + 2 * c2, dst + q * 16 * DKC, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(B + (size_t)r * NB + k0 + 2 * c2, dst + 64 * DKC + q * 16 * DKC, 16, 0, 0);
-    }
-  };
-  issue(0);
-  for (int ch = 0; ch < NCHK; ch++) {
-    if (ch + 1 < NCHK) {
-      issue(ch + 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk ch has landed; chunk ch + 1 (8 pieces) may still be in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    const double *cA = wbase + (ch & 1) * (2 * 64 * DKC), *cB = cA + 64 * DKC;
-#pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
-      double af[4], bf[4];
-#pragma unroll
-      for (int m = 0; m < 4; m++) af[m] = cA[off[kk][m]];
-#pragma unroll
-      for (int n = 0; n < 4; n++) bf[n] = cB[off[kk][n]];
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int n = 0; n < 4; n++) acc[m][n] = RT<double>::mfma(af[m], bf[n], acc[m][n]);
-    }
-  }
-}
-
 // ---- row-split panel kernels (latency path) ----------------------------------------------------------------------------
 // The panel solve and the one-column update have only (nt-k-1) tiles of work: one workgroup per tile leaves most CUs
 // idle and takes a full 128x128x128 product (27-33 us) on the critical path of every panel.  Here a workgroup owns
@@ -951,20 +889,29 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int
 // requested up front (tile_gemm_rows).  (Tried in round 3 and dropped for these short updates: running the rest of the update
 // on a second stream beside the next diagonal tile -- the fork / join costs what it hides: 19.17 against 18.95 ms per LM
 // iteration on the Venice shape with 24 % block fill.)
+// lead_len > 0 (look-ahead of the block-sparse schedule): only the tiles of the first one or two COLUMNS of the list are
+// updated -- (rows[ii], rows[0]), ii = 0 .. lead_len-1, then (rows[ii], rows[1]), ii = 1 .. lead_len-1 -- what the next pair's
+// panel chain needs; the rest of the update runs beside that chain (dense_ldl_factor_sparse).
 template <typename T>
 __global__ __launch_bounds__(256) void k_ldl_update_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
                                                         const T *__restrict__ V1, int k, int base, int nblk,
-                                                        const int *__restrict__ rows) {
+                                                        const int *__restrict__ rows, int lead_len = 0) {
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
   T *sA = lds, *sB = lds + 2 * RS * LDK;
   const int t = blockIdx.x >> 2, r0 = (blockIdx.x & 3) * RS;
   if (t >= nblk) return;
-  int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-  while (ii * (ii + 1) / 2 > t) ii--;
-  const int jj = t - ii * (ii + 1) / 2;
+  int ii, jj;
+  if (lead_len > 0) {
+    jj = t < lead_len ? 0 : 1;
+    ii = t < lead_len ? t : t - lead_len + 1;
+  } else {
+    ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+    while (ii * (ii + 1) / 2 > t) ii--;
+    jj = t - ii * (ii + 1) / 2;
+  }
   const int i = rows ? rows[ii] : base + ii, j = rows ? rows[jj] : base + jj;
   typename RT<T>::v4 acc[2][2];
 #pragma unroll
@@ -1242,20 +1189,62 @@ __global__ __launch_bounds__(256) void k_ldl_pairdiag(T *__restrict__ S, const i
   }
 }
 
+// one tile of the pair update: S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' (K = 256) by the four waves of a workgroup
+template <typename T>
+__device__ inline void ldl_update_tile(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, const T *__restrict__ V1,
+                                       int k, int i, int j, T *lds, const T *__restrict__ Lp0, const T *__restrict__ Lp1) {
+  BA_VT
+  T *Sij = S + tix(co, i, j) * NB * NB;
+  typename RT<T>::v4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  // Lp0 / Lp1 (distributed factorisation with per-rank ownership of S): the L tiles of the two panels come from the panel
+  // buffers the broadcast filled (tile row j at Lp + j NB^2) -- a rank holds only its own tile columns of S
+  tile_gemm_abt_priv<T, 2>(V0 + (int64_t)i * NB * NB, Lp0 ? Lp0 + (int64_t)j * NB * NB : S + tix(co, j, k) * NB * NB,
+                        V1 + (int64_t)i * NB * NB, Lp1 ? Lp1 + (int64_t)j * NB * NB : S + tix(co, j, k + 1) * NB * NB, lds, acc);
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
+  const int lane = tid2 & 63, wv = tid2 >> 6;
+  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  // epilogue: the 64 values of a lane are read-modify-written in two batches of 32 so that 32 loads are in flight at once
+  T *cbase = Sij + wr * NB + wc + (lane & 15);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    T cv[2][4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 2; n2++)
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) cv[n2][m][g] = NT_C ? __builtin_nontemporal_load(&cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)]) : cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)];
+#pragma unroll
+    for (int n2 = 0; n2 < 2; n2++)
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const T nv = cv[n2][m][g] - acc[m][2 * h + n2][g];
+          if (NT_C) __builtin_nontemporal_store(nv, &cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)]);
+          else cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)] = nv;
+        }
+  }
+}
+
 // Bulk trailing update, two panels per pass:  S_ij -= V0_i L_jk' + V1_i L_{j,k+1}'  for the lower-triangular tile pairs
 // base <= j <= i (K = 256): the trailing matrix is read and written once per TWO panels, which halves its HBM traffic per
-// flop.  (MODE is kept as a template parameter for the micro-benchmark variants; only MODE 1 exists.)
-// DBG (micro-benchmark only, ba_debug_update_bench): bit 0 = store instead of read-modify-write, bit 1 = every
-// workgroup reads the same operand tiles (L2-resident operands), bit 3 = workgroup-shared LDS staging with barriers
-// (the first version: 52.6 TFLOP/s against 59.8 for the wave-private staging that ships).
-// Where the remaining 24 % are NOT: the K loop's MFMA + LDS-read stream alone runs at 78.0 TFLOP/s (k_mfma_probe, modes
+// flop.  (MODE is kept as a template parameter; only MODE 1 exists.  The probe variants this kernel was tuned with --
+// store-only epilogue, L2-resident operands, workgroup-shared staging, LDS-DMA staging, K = 512, accumulators started from
+// -C -- live in csrc/bench/ba_bench_ldl.hip as k_ldl_update_probe, built into tools/libba_bench.so only.)
+// Where the remaining ~25 % are NOT: the K loop's MFMA + LDS-read stream alone runs at 78.0 TFLOP/s (k_mfma_probe, modes
 // 0 and 1: the operand reads are free); the two workgroups of a CU having their prologue / epilogue at the same time
 // (delaying every CU's second workgroup by 10 / 20 / 34 us changed nothing: 59.6-59.9); the read-modify-write epilogue
-// and the operands' home (variants 1, 2).  What is left is the staging inside the loop: every wave pulls its own A and B
-// slices, 16 KB per 64 MFMAs, ~9.7 TB/s of L2 -> LDS traffic chip-wide, with a wait for it at every chunk boundary.
+// and the operands' home (probe variants 1, 2).  What is left is the staging inside the loop: every wave pulls its own A
+// and B slices, 16 KB per 64 MFMAs, ~9.7 TB/s of L2 -> LDS traffic chip-wide, with a wait for it at every chunk boundary.
 // OWN (distributed factorisation): the launch covers only the tile columns this rank owns, listed ascending in own_cols
 // with own_pref[m] = number of tiles in the columns before own_cols[m]; the columns >= base start at index m0.
-template <typename T, int MODE, int DBG = 0, bool OWN = false>
+template <typename T, int MODE, bool OWN = false>
 __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
                                                         const T *__restrict__ V1, int k, int base, int nt,
                                                         int nblk, int *__restrict__ ready,
@@ -1267,7 +1256,6 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
   static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
-  T *sA = lds, *sB = lds + NB * LDK;
   int i, j, tsel;
   {
     // chunked block -> XCD map: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous
@@ -1296,83 +1284,34 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
       j = rows ? rows[jj] : base + jj;
     }
   }
-  T *Sij = S + tix(co, i, j) * NB * NB;
-  typename RT<T>::v4 acc[4][4];
-  if constexpr ((DBG & 64) != 0) {
-    // probe: the accumulators start as -C (loads in flight beside the first operand chunk), the epilogue stores -acc
-    const int lane0 = threadIdx.x & 63, wv0 = threadIdx.x >> 6;
-    const T *c0 = Sij + ((wv0 >> 1) * 64) * NB + (wv0 & 1) * 64 + (lane0 & 15);
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-      for (int n = 0; n < 4; n++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) acc[m][n][g] = -c0[(16 * m + RT<T>::row(lane0, g)) * NB + 16 * n];
-  } else {
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-      for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
-  }
-  const int io = (DBG & 2) ? base : i, jo = (DBG & 2) ? base : j;
-  if constexpr ((DBG & 16) != 0 && sizeof(T) == 8)
-    tile_gemm_abt_dma(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
-                      S + tix(co, jo, k + 1) * NB * NB, lds, acc);
-  else if constexpr ((DBG & 32) != 0)  // K = 512 probe (tools/bench_update.py variant 32): panels k .. k+3, V2 / V3 behind V1
-    tile_gemm_abt_priv<T, 4>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
-                          S + tix(co, jo, k + 1) * NB * NB, lds, acc, V1 + (int64_t)(nt + io) * NB * NB,
-                          S + tix(co, jo, k + 2) * NB * NB, V1 + (int64_t)(2 * nt + io) * NB * NB, S + tix(co, jo, k + 3) * NB * NB);
-  else if (!(DBG & 8))
-    // Lp0 / Lp1 (distributed factorisation with per-rank ownership of S): the L tiles of the two panels come from the panel
-    // buffers the broadcast filled (tile row j at Lp + j NB^2) -- a rank holds only its own tile columns of S
-    tile_gemm_abt_priv<T, 2>(V0 + (int64_t)io * NB * NB, Lp0 ? Lp0 + (int64_t)jo * NB * NB : S + tix(co, jo, k) * NB * NB,
-                          V1 + (int64_t)io * NB * NB, Lp1 ? Lp1 + (int64_t)jo * NB * NB : S + tix(co, jo, k + 1) * NB * NB, lds, acc);
-  else
-    tile_gemm_abt<T, 2>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
-                     S + tix(co, jo, k + 1) * NB * NB, sA, sB, acc);
-  int tid2 = threadIdx.x;
-  asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
-  const int lane = tid2 & 63, wv = tid2 >> 6;
-  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
-  // epilogue: the 64 values of a lane are read-modify-written in two batches of 32 so that 32 loads are in flight at once
-  T *cbase = Sij + wr * NB + wc + (lane & 15);
-  if constexpr ((DBG & 64) != 0) {
-#pragma unroll
-    for (int n = 0; n < 4; n++)
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * n] = -acc[m][n][g];
-  } else
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    T cv[2][4][4];
-    if (!(DBG & 1)) {
-#pragma unroll
-      for (int n2 = 0; n2 < 2; n2++)
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) cv[n2][m][g] = NT_C ? __builtin_nontemporal_load(&cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)]) : cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)];
-    }
-#pragma unroll
-    for (int n2 = 0; n2 < 2; n2++)
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const T a = acc[m][2 * h + n2][g];
-          const T nv = (DBG & 1) ? a : cv[n2][m][g] - a;
-          if (NT_C) __builtin_nontemporal_store(nv, &cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)]);
-          else cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)] = nv;
-        }
-  }
+  ldl_update_tile<T>(S, co, V0, V1, k, i, j, lds, Lp0, Lp1);
   // tiles 0 .. ready_tiles-1 are (base,base) [, (base+1,base), (base+1,base+1)]: what the next pair's hoisted diagonal
   // kernel waits for.  Each tells it so once its tile is final.
   if (ready && tsel < ready_tiles) {
     __threadfence();  // every thread's stores, agent scope (written back past this XCD's L2)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The same update for the look-ahead of the block-sparse schedule (dense_ldl_factor_sparse): the "rest" of a pair's
+// trailing update runs BESIDE the next pair's panel chain, whose diagonal-tile kernel needs a whole CU to itself (153 KB of
+// LDS in Float64) -- beside a launch that fills the chip it would wait until some CU has drained, i.e. until the update is
+// over.  So this form keeps to a part of the chip: a fixed number of workgroups (grid), each asking for more than half a
+// CU's LDS so that no two share a CU, walking the tiles t = block, block + grid, ...; the CUs it leaves alone take the
+// chain.  Same tile routine, same enumeration (triangular index over the row list): same bits as k_ldl_update.
+constexpr size_t PART_LDS_BYTES = 84 * 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_update_part(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
+                                                          const T *__restrict__ V1, int k, int nblk, const int *__restrict__ rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  for (int t = blockIdx.x; t < nblk; t += gridDim.x) {
+    int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+    while (ii * (ii + 1) / 2 > t) ii--;
+    const int jj = t - ii * (ii + 1) / 2;
+    ldl_update_tile<T>(S, co, V0, V1, k, rows[ii], rows[jj], lds, nullptr, nullptr);
   }
 }
 
@@ -1560,7 +1499,9 @@ static int set_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PT_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_rs<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RS_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 0, true>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_part<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_priv_lds_bytes<T>()));
   g_attr_done.store(true);
   return BA_OK;
@@ -1641,6 +1582,11 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
   BA_HIP_CHECK(hipMalloc((void **)&w->flag, sizeof(int)));
   BA_HIP_CHECK(hipMalloc((void **)&w->ready, (size_t)nt * sizeof(int)));
   BA_HIP_CHECK(hipStreamCreateWithFlags(&w->hoist, hipStreamNonBlocking));
+  {  // the stream of the block-sparse schedule's look-ahead: lowest priority, so that the panel chain's kernels are placed first
+    int lo = 0, hi = 0;
+    BA_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    BA_HIP_CHECK(hipStreamCreateWithPriority(&w->rest, hipStreamNonBlocking, lo));
+  }
   BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_top, hipEventDisableTiming | hipEventReleaseToDevice));
   // the distributed factorisation's events order work whose data LEAVES the device (panels handed to the transport):
   // default release scope, not hipEventReleaseToDevice as the single-GPU hoist events above
@@ -1683,6 +1629,7 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->lcol) (void)hipFree(w->lcol);
   if (w->lpair) (void)hipFree(w->lpair);
   if (w->hoist) (void)hipStreamDestroy(w->hoist);
+  if (w->rest) (void)hipStreamDestroy(w->rest);
   if (w->ev_top) (void)hipEventDestroy(w->ev_top);
   if (w->ev_chain) (void)hipEventDestroy(w->ev_chain);
   if (w->ev_dtop) (void)hipEventDestroy(w->ev_dtop);
@@ -1949,19 +1896,56 @@ int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {
   return BA_OK;
 }
 
-// the in-order pair schedule over the pattern (see above); d_b != null: the forward substitution rides along
+// The pair schedule over the pattern (see above); d_b != null: the forward substitution rides along.
+//
+// Look-ahead of one pair (BA_SPARSE_LOOKAHEAD=0 disables; never with per-kernel profiling): of pair q's trailing update the
+// next pair's panel chain needs only the tiles of tile columns k+2, k+3 -- the "lead" part, at most two columns of the row
+// list, done at once on the main stream -- while the rest (the lower triangle over the remaining rows) runs on the second
+// stream beside that chain: diag(k+2), panel solve, column update, diag(k+3), panel solve are one workgroup or a few dozen
+// each and leave the chip almost empty.  Ordering: rest(q) starts when pair q's panels are complete (event), lead(q+1)
+// waits for rest(q) (both update tiles of columns k+4, k+5), rests follow one another on their stream, and the panel
+// buffers alternate between pairs (rest(q) reads the buffers pair q+2 writes: it has been waited for by then).  The two
+// parts touch disjoint tiles and each tile receives its updates in the same order as in the in-order schedule: same bits.
+// Forks and joins are events, so the whole factorisation still records into one hipGraph.
 template <typename T>
 int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b) {
   const int nt = (int)w->nt;
   const TilePattern *pat = w->pat;
-  T *V0 = w->V, *V1 = w->V + (int64_t)nt * NB * NB;
+  const int64_t panel = (int64_t)nt * NB * NB;
   T *y = w->D + w->nt * NB;
   w->hoisting = false;
+  const char *la_env = getenv("BA_SPARSE_LOOKAHEAD");  // read per call: tests compare both schedules in one process
+  const bool lookahead = !p->prof_on && !(la_env && la_env[0] == '0');
+  static const int la_min = [] { const char *e = getenv("BA_SPARSE_LOOKAHEAD_MIN"); return e ? atoi(e) : 48; }();  // tiles of a rest worth a fork
+  static const int rest_cus = [] { const char *e = getenv("BA_SPARSE_REST_CUS"); return e ? atoi(e) : 192; }();  // CUs the rest may take
+  bool pending[2] = {false, false};  // rest of pair q (slot q & 1) launched on the second stream and not yet joined
+  auto join_rest = [&](int slot) -> int {
+    if (pending[slot]) {
+      BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_upd[slot], 0));
+      pending[slot] = false;
+    }
+    return BA_OK;
+  };
+  auto launch_update = [&](hipStream_t s2, const T *V0, const T *V1, int k, const int *rows, int cnt) {
+    const int nblk = cnt * (cnt + 1) / 2;
+    if (nblk <= 0) return;
+    ProfScope ps(p, nblk <= update_rs_max() ? PC_LDL_UPDATE_RS : PC_LDL_UPDATE, s2);
+    if (nblk <= update_rs_max())
+      hipLaunchKernelGGL(k_ldl_update_rs<T>, dim3(4 * nblk), dim3(256), RS_LDS_ELEMS * sizeof(T), s2, w->S, w->col_off, V0, V1, k, k + 2,
+                         nblk, rows, 0);
+    else
+      hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), s2, w->S,
+                         w->col_off, V0, V1, k, k + 2, nt, nblk, (int *)nullptr, (const int *)nullptr, (const int64_t *)nullptr, 0, 0,
+                         1, rows);
+  };
   for (int k = 0, q = 0; k < nt; k += 2, q++) {
+    const int slot = q & 1;
+    T *V0 = w->V + 2 * slot * panel, *V1 = V0 + panel;
     const int l0 = pat->prow_ptr[(size_t)q], l1 = pat->prow_ptr[(size_t)q + 1];
     const int c1 = l1 - l0;                      // {k+1} + U_q
     const int c2 = c1 > 0 ? c1 - 1 : 0;          // U_q
     const int *rows1 = w->prow + l0, *rows2 = w->prow + l0 + 1;
+    BA_CHECK(join_rest(slot));  // (the rest of pair q-2 read these panel buffers; joined long ago: see lead below)
     launch_diag(p, w, k, st, nullptr, k == 0);  // (the first one clears the pivot flag)
     if (c1 == 0) {  // last, single tile column: y_k only
       if (d_b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k, (const int *)nullptr);
@@ -1994,18 +1978,36 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
         hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * c2), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
                            w->Linv + (int64_t)(k + 1) * NB * NB, w->D + (int64_t)(k + 1) * NB, V1, k + 1, d_b, y, rows2);
     }
-    {
-      const int nblk = c2 * (c2 + 1) / 2;
-      ProfScope ps(p, nblk <= update_rs_max() ? PC_LDL_UPDATE_RS : PC_LDL_UPDATE, st);
-      if (nblk <= update_rs_max())
+    // the rows of U_q that are the next pair's own tile columns (k+2, k+3): at the head of the ascending list
+    int nlead = 0;
+    while (nlead < c2 && nlead < 2 && pat->prow[(size_t)(l0 + 1 + nlead)] < k + 4) nlead++;
+    const int nrest = c2 - nlead;
+    if (lookahead && nrest * (nrest + 1) / 2 >= la_min) {
+      // the lead first, alone on the chip (beside the rest it takes as long as the whole update: measured), then the rest
+      // beside the next chain
+      BA_CHECK(join_rest(slot ^ 1));  // rest(q-1) has updated the lead tiles too (and the next chain reads its columns)
+      if (nlead > 0) {
+        const int nblk = nlead == 1 ? c2 : 2 * c2 - 1;
+        ProfScope ps(p, PC_LDL_UPDATE_RS, st);
         hipLaunchKernelGGL(k_ldl_update_rs<T>, dim3(4 * nblk), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, V0, V1, k, k + 2,
-                           nblk, rows2);
-      else
-        hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S,
-                           w->col_off, V0, V1, k, k + 2, nt, nblk, (int *)nullptr, (const int *)nullptr, (const int64_t *)nullptr, 0, 0,
-                           1, rows2);
+                           nblk, rows2, c2);
+      }
+      BA_HIP_CHECK(hipEventRecord(w->ev_recv[slot], st));  // both panels of pair q complete, its lead tiles updated
+      BA_HIP_CHECK(hipStreamWaitEvent(w->rest, w->ev_recv[slot], 0));
+      {
+        const int nblk = nrest * (nrest + 1) / 2;
+        hipLaunchKernelGGL(k_ldl_update_part<T>, dim3(nblk < rest_cus ? nblk : rest_cus), dim3(256), PART_LDS_BYTES, w->rest, w->S, w->col_off,
+                           V0, V1, k, nblk, rows2 + nlead);
+      }
+      BA_HIP_CHECK(hipEventRecord(w->ev_upd[slot], w->rest));
+      pending[slot] = true;
+    } else {
+      BA_CHECK(join_rest(slot ^ 1));
+      launch_update(st, V0, V1, k, rows2, c2);
     }
   }
+  BA_CHECK(join_rest(0));
+  BA_CHECK(join_rest(1));
   BA_HIP_CHECK(hipGetLastError());
   if (zero_pivot) {
     int h = 0;
@@ -2029,7 +2031,7 @@ static int launch_pair_owned(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0,
     Lp0 = w->Lb + (V0 - w->V);
     Lp1 = w->Lb + (V1 - w->V);
   }
-  hipLaunchKernelGGL((k_ldl_update<T, 1, 0, true>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st,
+  hipLaunchKernelGGL((k_ldl_update<T, 1, true>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st,
                      w->S, w->col_off, V0, V1, k, w->h_own_cols[(size_t)m0], (int)w->nt, nblk, (int *)nullptr, w->own_cols, w->own_pref, m0, m1,
                      1, (const int *)nullptr, Lp0, Lp1);
   return BA_OK;

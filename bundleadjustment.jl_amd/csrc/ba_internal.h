@@ -94,6 +94,7 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   int *flag = nullptr;     // device int: set to 1 on an exactly zero pivot (2: a hoisted diagonal tile never became ready)
   int *ready = nullptr;    // nt device ints: tile (k,k) has received its last trailing update (hoisted-diagonal schedule)
   hipStream_t hoist = nullptr;   // second stream of the hoisted-diagonal schedule (no CU mask)
+  hipStream_t rest = nullptr;    // look-ahead of the block-sparse schedule: the rest of a pair's update (lowest priority)
   hipEvent_t ev_top = nullptr;
   bool hoist_disabled = false;   // a hoisted kernel once timed out (kernels serialised by a profiler): never again on this handle
   bool hoisting = false;         // the factorisation forks onto `hoist` (set by dense_ldl_factor's schedule choice)

@@ -4,6 +4,198 @@
 #include <time.h>
 #include "../ba_dense_ldl.hip"
 
+// ---- probe variants of the bulk trailing update (micro-benchmark only: tools/bench_update.py) -----------------------------
+// DBG: bit 0 = store instead of read-modify-write, bit 1 = every workgroup reads the same operand tiles (L2-resident
+// operands), bit 3 = workgroup-shared LDS staging with barriers (the first version: 52.6 TFLOP/s against 59.8 for the
+// wave-private staging that ships), bit 4 = LDS-DMA staging, bit 5 = K = 512 (four panels per pass), bit 6 = accumulators
+// started from -C.  DBG = 0 is the product kernel k_ldl_update itself.
+namespace {
+// LDS-DMA variant of the wave-private product (Float64): the operand chunks go global -> LDS directly
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write, no wait between a load and its LDS write), chunks of 8, two LDS
+// buffers per wave (16 KB per wave, 64 KB per workgroup); the next chunk's 8 pieces are in flight during the MFMAs and the
+// wave waits with vmcnt only.  A piece lands at base + lane * 16 bytes, so rows are unpadded (64 B): the 16-byte columns are
+// XOR-swizzled with the row ((row >> 2) & 3), which keeps the MFMA operand reads at two dwords per bank.  Same products in
+// the same order as tile_gemm_abt_priv (bit-identical accumulators; tools/bench_mfma_probe.py modes 3 / 5 compare their
+// checksums).  Probe, nonzero operands, steady state: 68.6-68.7 TFLOP/s against 66.1-66.2 for the register-staged loop.
+constexpr int DKC = 8;
+constexpr size_t GEMM_DMA_LDS_ELEMS = (size_t)4 * 2 * 2 * 64 * DKC;
+__device__ inline void tile_gemm_abt_dma(const double *__restrict__ A0, const double *__restrict__ B0,
+                                         const double *__restrict__ A1, const double *__restrict__ B1, double *lds,
+                                         RT<double>::v4 acc[4][4]) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  const int fr = lane & 15, fk = lane >> 4;
+  double *wbase = lds + wv * (2 * 2 * 64 * DKC);  // [buffer][A | B][64 rows][8]
+  const int prow = lane >> 2, pc2 = lane & 3;     // a piece: 16 rows x 64 B; this lane's row and 16-byte slot inside it
+  int off[2][4];  // operand read offsets inside a 64 x 8 slice: row r, element k -> r*8 + (((k>>1) ^ ((r>>2)&3)) << 1) + (k&1)
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int r = 16 * m + fr, k = 4 * kk + fk;
+      off[kk][m] = r * DKC + (((k >> 1) ^ ((r >> 2) & 3)) << 1) + (k & 1);
+    }
+  constexpr int NCHK = 2 * NB / DKC, HALF = NB / DKC;
+  auto issue = [&](int ch) {  // 8 DMA pieces: chunk ch of A and B into buffer ch & 1
+    double *dst = wbase + (ch & 1) * (2 * 64 * DKC);
+    const double *A = (ch < HALF ? A0 : A1) + (size_t)wr * NB, *B = (ch < HALF ? B0 : B1) + (size_t)wc * NB;
+    const int k0 = (ch & (HALF - 1)) * DKC;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = 16 * q + prow;
+      const int c2 = pc2 ^ ((r >> 2) & 3);
+      __builtin_amdgcn_global_load_lds(A + (size_t)r * NB + k0 + 2 * c2, dst + q * 16 * DKC, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(B + (size_t)r * NB + k0 + 2 * c2, dst + 64 * DKC + q * 16 * DKC, 16, 0, 0);
+    }
+  };
+  issue(0);
+  for (int ch = 0; ch < NCHK; ch++) {
+    if (ch + 1 < NCHK) {
+      issue(ch + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk ch has landed; chunk ch + 1 (8 pieces) may still be in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const double *cA = wbase + (ch & 1) * (2 * 64 * DKC), *cB = cA + 64 * DKC;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) af[m] = cA[off[kk][m]];
+#pragma unroll
+      for (int n = 0; n < 4; n++) bf[n] = cB[off[kk][n]];
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = RT<double>::mfma(af[m], bf[n], acc[m][n]);
+    }
+  }
+}
+
+
+template <typename T, int MODE, int DBG, bool OWN = false>
+__global__ __launch_bounds__(256, 2) void k_ldl_update_probe(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
+                                                        const T *__restrict__ V1, int k, int base, int nt,
+                                                        int nblk, int *__restrict__ ready,
+                                                        const int *__restrict__ own_cols = nullptr,
+                                                        const int64_t *__restrict__ own_pref = nullptr, int m0 = 0,
+                                                        int m_end = 0, int ready_tiles = 1, const int *__restrict__ rows = nullptr,
+                                                        const T *__restrict__ Lp0 = nullptr, const T *__restrict__ Lp1 = nullptr) {
+  BA_VT
+  static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  T *sA = lds, *sB = lds + NB * LDK;
+  int i, j, tsel;
+  {
+    // chunked block -> XCD map: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous
+    // range of tile rows so that V_i stays in its L2 (speed only)
+    const int per = (nblk + 7) / 8;
+    int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= nblk) return;
+    tsel = t;
+    if (OWN) {
+      const int64_t tt = t + own_pref[m0];
+      int lo = m0, hi = m_end;  // largest m with own_pref[m] <= tt
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (own_pref[mid] <= tt) lo = mid;
+        else hi = mid;
+      }
+      j = own_cols[lo];
+      i = j + (int)(tt - own_pref[lo]);
+    } else {
+      int ii = (int)((sqrt(8.0 * (T)t + 1.0) - 1.0) * 0.5);
+      while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+      while (ii * (ii + 1) / 2 > t) ii--;
+      const int jj = t - ii * (ii + 1) / 2;
+      // rows (block-sparse S): the pair's pattern, ascending -- tile (rows[ii], rows[jj]) instead of (base + ii, base + jj)
+      i = rows ? rows[ii] : base + ii;
+      j = rows ? rows[jj] : base + jj;
+    }
+  }
+  T *Sij = S + tix(co, i, j) * NB * NB;
+  typename RT<T>::v4 acc[4][4];
+  if constexpr ((DBG & 64) != 0) {
+    // probe: the accumulators start as -C (loads in flight beside the first operand chunk), the epilogue stores -acc
+    const int lane0 = threadIdx.x & 63, wv0 = threadIdx.x >> 6;
+    const T *c0 = Sij + ((wv0 >> 1) * 64) * NB + (wv0 & 1) * 64 + (lane0 & 15);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[m][n][g] = -c0[(16 * m + RT<T>::row(lane0, g)) * NB + 16 * n];
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int n = 0; n < 4; n++) acc[m][n] = (d4){0, 0, 0, 0};
+  }
+  const int io = (DBG & 2) ? base : i, jo = (DBG & 2) ? base : j;
+  if constexpr ((DBG & 16) != 0 && sizeof(T) == 8)
+    tile_gemm_abt_dma(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                      S + tix(co, jo, k + 1) * NB * NB, lds, acc);
+  else if constexpr ((DBG & 32) != 0)  // K = 512 probe (tools/bench_update.py variant 32): panels k .. k+3, V2 / V3 behind V1
+    tile_gemm_abt_priv<T, 4>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                          S + tix(co, jo, k + 1) * NB * NB, lds, acc, V1 + (int64_t)(nt + io) * NB * NB,
+                          S + tix(co, jo, k + 2) * NB * NB, V1 + (int64_t)(2 * nt + io) * NB * NB, S + tix(co, jo, k + 3) * NB * NB);
+  else if (!(DBG & 8))
+    // Lp0 / Lp1 (distributed factorisation with per-rank ownership of S): the L tiles of the two panels come from the panel
+    // buffers the broadcast filled (tile row j at Lp + j NB^2) -- a rank holds only its own tile columns of S
+    tile_gemm_abt_priv<T, 2>(V0 + (int64_t)io * NB * NB, Lp0 ? Lp0 + (int64_t)jo * NB * NB : S + tix(co, jo, k) * NB * NB,
+                          V1 + (int64_t)io * NB * NB, Lp1 ? Lp1 + (int64_t)jo * NB * NB : S + tix(co, jo, k + 1) * NB * NB, lds, acc);
+  else
+    tile_gemm_abt<T, 2>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                     S + tix(co, jo, k + 1) * NB * NB, sA, sB, acc);
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
+  const int lane = tid2 & 63, wv = tid2 >> 6;
+  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  // epilogue: the 64 values of a lane are read-modify-written in two batches of 32 so that 32 loads are in flight at once
+  T *cbase = Sij + wr * NB + wc + (lane & 15);
+  if constexpr ((DBG & 64) != 0) {
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * n] = -acc[m][n][g];
+  } else
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    T cv[2][4][4];
+    if (!(DBG & 1)) {
+#pragma unroll
+      for (int n2 = 0; n2 < 2; n2++)
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) cv[n2][m][g] = NT_C ? __builtin_nontemporal_load(&cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)]) : cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)];
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < 2; n2++)
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const T a = acc[m][2 * h + n2][g];
+          const T nv = (DBG & 1) ? a : cv[n2][m][g] - a;
+          if (NT_C) __builtin_nontemporal_store(nv, &cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)]);
+          else cbase[(16 * m + RT<T>::row(lane, g)) * NB + 16 * (2 * h + n2)] = nv;
+        }
+  }
+  // tiles 0 .. ready_tiles-1 are (base,base) [, (base+1,base), (base+1,base+1)]: what the next pair's hoisted diagonal
+  // kernel waits for.  Each tells it so once its tile is final.
+  if (ready && tsel < ready_tiles) {
+    __threadfence();  // every thread's stores, agent scope (written back past this XCD's L2)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace
+
 namespace {
 __global__ void k_probe_fill(double *a, size_t n, double scale) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -23,23 +215,23 @@ __global__ void k_probe_fill(double *a, size_t n, double scale) {
 static int set_bench_kernel_attrs() {
   typedef double T;
   BA_CHECK(set_kernel_attrs<T>());
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 1>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 2>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 8>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 8>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 16>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 16>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 17>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 17>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 32>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 32>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 33>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 33>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 64>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 64>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
-  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, 9>),
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 9>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS_ELEMS * sizeof(T))));
   return BA_OK;
 }
@@ -74,21 +266,21 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
   auto launch = [&]() {
     const double *V0 = V, *V1 = V + (size_t)nt * NB * NB;
     switch (variant) {
-      case 1: hipLaunchKernelGGL((k_ldl_update<double, 1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      case 2: hipLaunchKernelGGL((k_ldl_update<double, 1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      case 8: hipLaunchKernelGGL((k_ldl_update<double, 1, 8>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      case 16: hipLaunchKernelGGL((k_ldl_update<double, 1, 16>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      case 17: hipLaunchKernelGGL((k_ldl_update<double, 1, 17>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      case 32: hipLaunchKernelGGL((k_ldl_update<double, 1, 32>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
-      case 33: hipLaunchKernelGGL((k_ldl_update<double, 1, 33>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
-      case 64: hipLaunchKernelGGL((k_ldl_update<double, 1, 64>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      case 9: hipLaunchKernelGGL((k_ldl_update<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
-      default: hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr);
+      case 1: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 2: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 2>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 8: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 8>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 16: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 16>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 17: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 17>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 32: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 32>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
+      case 33: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 33>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
+      case 64: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 64>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 9: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      default: hipLaunchKernelGGL((k_ldl_update<double, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr);
     }
   };
   {
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_ldl_update<double, 1, 0>), 256, GEMM_LDS_ELEMS * sizeof(double));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_ldl_update<double, 1>), 256, GEMM_LDS_ELEMS * sizeof(double));
     if (variant == 0) fprintf(stderr, "[debug] update<1>: occupancy API says %d workgroups/CU at %zu B LDS\n", nb, GEMM_PRIV_LDS_ELEMS * sizeof(double));
   }
   launch();
@@ -161,7 +353,7 @@ extern "C" int ba_debug_update_seq(int nt, int n, const int *m_list, const int *
     }
     const int m = m_list[q], nblk = m * (m + 1) / 2, grid = ((nblk + 7) / 8) * 8;
     BA_HIP_CHECK(hipEventRecord(ev[(size_t)2 * q], 0));
-    hipLaunchKernelGGL((k_ldl_update<double, 1, 0>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0,
+    hipLaunchKernelGGL((k_ldl_update<double, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0,
                        nt - m, nt, nblk, (int *)nullptr);
     BA_HIP_CHECK(hipEventRecord(ev[(size_t)2 * q + 1], 0));
   }

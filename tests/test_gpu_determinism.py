@@ -69,6 +69,67 @@ def test_lm_step_twice_same_bits_venice_scaled(ba, gpu_ok):
 
 
 
+def _env(key, value, fn):
+    old = os.environ.get(key)
+    if value is None:
+        os.environ.pop(key, None)
+    else:
+        os.environ[key] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = old
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_block_sparse_lookahead_same_bits_as_in_order(ba, gpu_ok, shuffle):
+    """The list schedule of the block-sparse reduced camera system with its look-ahead (the rest of a pair's trailing update
+    on a second stream beside the next pair's panel chain, joined by events; dense_ldl_factor_sparse) against the strictly
+    in-order form (BA_SPARSE_LOOKAHEAD=0): every tile receives the same updates in the same order, so the steps must be the
+    SAME BITS -- plain launches and recorded graphs, Float64 and Float32, twice in a row.  Problem: 700 cameras (n = 6300,
+    50 tile rows), cameras of a point within 20 % of the cameras (rests long enough to fork), as generated and with the
+    cameras renumbered at random (then the ordering's sequence gives the pattern)."""
+    p = ba.synthetic.make_problem(700, 7000, 40000, seed=33, locality=0.2)
+    if shuffle:
+        p, _ = ba.synthetic.shuffle_cameras(p, seed=4)
+    arrays = ba.synthetic.as_arrays(p)
+
+    def step(facto_type=None):
+        m = ba.BALNLPModel(arrays=arrays)
+        d1, h1, _ = ba.lm_step(m, p["x0"], 10.0, facto_type=facto_type)
+        d2, h2, _ = ba.lm_step(m, p["x0"], 10.0, facto_type=facto_type)
+        pat = ba.schur_pattern(m)
+        m.close()
+        return d1, d2, h1, h2, pat
+
+    def run(graph=None):
+        m = ba.BALNLPModel(arrays=arrays)
+        st = _env("BA_LM_GRAPH", graph, lambda: ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "LDL", "AMD", "None", False, ite_max=5))
+        m.close()
+        return st
+
+    for ft in (None, np.float32):
+        a1, a2, ha1, ha2, pat = _env("BA_SPARSE_S", "1", lambda: step(ft))
+        b1, b2, hb1, hb2, _ = _env("BA_SPARSE_LOOKAHEAD", "0", lambda: _env("BA_SPARSE_S", "1", lambda: step(ft)))
+        assert pat[2] and np.all(np.isfinite(a1))
+        tag = "Float32" if ft is not None else "Float64"
+        for name, (x, y) in {"look-ahead twice": (a1, a2), "in order twice": (b1, b2), "look-ahead vs in order": (a1, b1)}.items():
+            rep = bits_report(x, y, f"{tag} block-sparse step, {name}")
+            assert not rep, rep
+        assert ha1 == ha2 == hb1 == hb2
+    # complete runs: recorded graphs (the forks and joins become graph edges) and plain launches, against the in-order schedule
+    s_graph = _env("BA_SPARSE_S", "1", lambda: run(None))
+    s_plain = _env("BA_SPARSE_S", "1", lambda: run("0"))
+    s_inord = _env("BA_SPARSE_LOOKAHEAD", "0", lambda: _env("BA_SPARSE_S", "1", lambda: run(None)))
+    assert s_graph.iter == s_plain.iter == s_inord.iter and s_graph.log == s_plain.log == s_inord.log
+    for name, (x, y) in {"graph vs plain launches": (s_graph.solution, s_plain.solution), "look-ahead vs in order": (s_graph.solution, s_inord.solution)}.items():
+        rep = bits_report(x, y, f"solution of a 6-iteration run, {name}")
+        assert not rep, rep
+
+
 @pytest.mark.parametrize("variant", ["lm.jl", "LevenbergMarquardt.jl", "lm.jl linesearch"])
 def test_prefetched_trial_step_same_rows_as_two_submissions(ba, gpu_ok, variant):
     """Recorded launch sequences (small problems): after an accepted step the refresh of J and the NEXT trial step are

