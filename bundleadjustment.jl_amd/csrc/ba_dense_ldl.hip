@@ -1900,13 +1900,21 @@ int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {
 //
 // Look-ahead of one pair (BA_SPARSE_LOOKAHEAD=0 disables; never with per-kernel profiling): of pair q's trailing update the
 // next pair's panel chain needs only the tiles of tile columns k+2, k+3 -- the "lead" part, at most two columns of the row
-// list, done at once on the main stream -- while the rest (the lower triangle over the remaining rows) runs on the second
+// list, done at once on the main stream -- while the rest (the lower triangle over the remaining rows) runs on a second
 // stream beside that chain: diag(k+2), panel solve, column update, diag(k+3), panel solve are one workgroup or a few dozen
-// each and leave the chip almost empty.  Ordering: rest(q) starts when pair q's panels are complete (event), lead(q+1)
-// waits for rest(q) (both update tiles of columns k+4, k+5), rests follow one another on their stream, and the panel
-// buffers alternate between pairs (rest(q) reads the buffers pair q+2 writes: it has been waited for by then).  The two
-// parts touch disjoint tiles and each tile receives its updates in the same order as in the in-order schedule: same bits.
-// Forks and joins are events, so the whole factorisation still records into one hipGraph.
+// each and leave the chip almost empty.  The rest keeps to a part of the chip (k_ldl_update_part: the diagonal-tile kernel
+// needs a whole CU).  Ordering: lead(q) waits for rest(q-1) (both update tiles of columns k+2, k+3), rest(q) starts behind
+// lead(q) (beside it the lead took as long as the whole update), rests follow one another on their stream, and the panel
+// buffers alternate between pairs (rest(q) reads the buffers pair q+2 writes: it has been joined by then).  The parts touch
+// disjoint tiles and each tile receives its updates in the same order as in the in-order schedule: same bits (tested).
+// Forks and joins are events, so the factorisation still records into one hipGraph.
+// What it buys (kernel trace, Final-13682 shape with 6 % tile fill, Float32): the in-order pair takes 137 us -- diag 28,
+// solve 11, column 8, diag 28, solve 11, update 53; with the look-ahead the 48 us rest disappears behind the next chain, the
+// 12 us lead stays, and every fork / join of the replayed graph costs ~12 us of cross-queue synchronisation: 131 us per pair,
+// 101 -> 93 ms per LM iteration.  Rests shorter than BA_SPARSE_LOOKAHEAD_MIN tiles (256: the Venice shape's are 120) are
+// not worth their two synchronisations and stay in order.  What would shorten the chain itself -- independent subtrees of
+// the elimination tree on several streams -- needs per-subtree contribution blocks for the separator tiles (two subtrees
+// update the same tiles): not built.
 template <typename T>
 int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b) {
   const int nt = (int)w->nt;
@@ -1916,7 +1924,7 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
   w->hoisting = false;
   const char *la_env = getenv("BA_SPARSE_LOOKAHEAD");  // read per call: tests compare both schedules in one process
   const bool lookahead = !p->prof_on && !(la_env && la_env[0] == '0');
-  static const int la_min = [] { const char *e = getenv("BA_SPARSE_LOOKAHEAD_MIN"); return e ? atoi(e) : 48; }();  // tiles of a rest worth a fork
+  static const int la_min = [] { const char *e = getenv("BA_SPARSE_LOOKAHEAD_MIN"); return e ? atoi(e) : 256; }();  // tiles of a rest worth a fork (below: one launch on the main stream, as before)
   static const int rest_cus = [] { const char *e = getenv("BA_SPARSE_REST_CUS"); return e ? atoi(e) : 192; }();  // CUs the rest may take
   bool pending[2] = {false, false};  // rest of pair q (slot q & 1) launched on the second stream and not yet joined
   auto join_rest = [&](int slot) -> int {
