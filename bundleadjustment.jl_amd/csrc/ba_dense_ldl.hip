@@ -1924,7 +1924,7 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
   w->hoisting = false;
   const char *la_env = getenv("BA_SPARSE_LOOKAHEAD");  // read per call: tests compare both schedules in one process
   const bool lookahead = !p->prof_on && !(la_env && la_env[0] == '0');
-  static const int la_min = [] { const char *e = getenv("BA_SPARSE_LOOKAHEAD_MIN"); return e ? atoi(e) : 256; }();  // tiles of a rest worth a fork (below: one launch on the main stream, as before)
+  const int la_min = [] { const char *e = getenv("BA_SPARSE_LOOKAHEAD_MIN"); return e ? atoi(e) : 256; }();  // (read per call: the tests force it to 1)   // tiles of a rest worth a fork (below: one launch on the main stream, as before)
   static const int rest_cus = [] { const char *e = getenv("BA_SPARSE_REST_CUS"); return e ? atoi(e) : 192; }();  // CUs the rest may take
   bool pending[2] = {false, false};  // rest of pair q (slot q & 1) launched on the second stream and not yet joined
   auto join_rest = [&](int slot) -> int {

@@ -393,20 +393,39 @@ __global__ __launch_bounds__(BLK) void k_obs_y(int64_t nobs, const int *__restri
 // J_a (24), the camera rows of J_b (18) and Y_b (6) is staged in the wave's LDS slot.
 typedef double d4s __attribute__((ext_vector_type(4)));
 #ifndef BA_SCHUR_PF
-#define BA_SCHUR_PF 2  // task pairs in flight per wave: 2, 3, 4 measure the same (6.29-6.42 ms on the sweep box), 6 and 8 slower (7.7)
+#define BA_SCHUR_PF 4  // task pairs in flight per wave (ring of LDS slots, see schur_accumulate)
 #endif
 constexpr int SCHUR_PF = BA_SCHUR_PF;
+constexpr int SCHUR_SLOT = 128;                       // doubles per ring slot: 64 lanes x 16 bytes
+constexpr int SCHUR_RING = SCHUR_PF * SCHUR_SLOT;     // doubles per wave
 // sum over the tasks [t_begin, t_end) of B_a' (Q_ab B_b): lane (fr < 9, i = fk + 4 g < 9) gets element (i, j = fr) in acc[g]
+//
+// A task's record -- J_a (24 doubles), the camera columns of J_b (2 x 9) and Y_b (6) -- is gathered as 25 aligned 16-byte
+// pieces: 12 of J_a, 5 + 5 of J_b (doubles 2..11 and 14..23: one point column rides along in each half so that the pieces
+// stay aligned), 3 of Y_b.  ONE load instruction fetches a PAIR of tasks (lanes 0..24 the first, 32..56 the second) and
+// delivers it straight into the wave's LDS ring (global_load_lds_dwordx4: no staging registers, no ds_write), SCHUR_PF
+// pairs ahead; the wave waits with vmcnt only.  Record in its slot (doubles, task tl at 64 tl): J_a at 0..23, J_b[3 + i] at
+// 25 + i, J_b[15 + i] at 35 + i, Y_b at 44..49.
+// (Round 3's form staged single elements through a rotating set of prefetch REGISTERS (pf[q] = pf[q + 1]); a move of a
+// register whose load is in flight makes the compiler wait for that load, so the generated loop began with s_waitcnt
+// vmcnt(0): every trip waited for the loads issued one trip earlier -- a whole memory round trip, ~4 700 cycles per task
+// pair and wave in the kernel trace -- whatever the depth of the ring; which is why depths 2, 3, 4 had measured the same.)
 __device__ inline d4s schur_accumulate(int t_begin, int t_end, const int *__restrict__ task_a, const int *__restrict__ task_b,
-                                       const double *__restrict__ J, const double *__restrict__ Y, double (*stage)[48]) {
+                                       const double *__restrict__ J, const double *__restrict__ Y, double *ring) {
   const int lane = threadIdx.x & 63;
   const int fr = lane & 15, fk = lane >> 4, tl = fk >> 1, al = fk & 1;
-  // element `lane` (< 48) of a task record: J_a[0..23] | J_b camera rows (2 x 9) | Y_b[0..5]
-  const int e = lane;
-  const int eoff = e < 24 ? e : (e < 33 ? e - 24 + 3 : (e < 42 ? e - 33 + 15 : e - 42));
   d4s acc = {0, 0, 0, 0};
-  // Latency hiding inside one wave: task indices come 64 at a time with one coalesced load and are handed out with
-  // v_readlane; the records of the next task pairs are in flight (registers) while the current pair is multiplied.
+  // (the task range is wave-uniform but arrives in vector registers: made scalar, or every trip count below is a lane mask)
+  t_begin = __builtin_amdgcn_readfirstlane(t_begin);
+  t_end = __builtin_amdgcn_readfirstlane(t_end);
+  // this lane's piece as ONE address expression, J + 8 (mul * observation + add), the Y block reached through its distance
+  // from J: a fetch is two v_readlane, a select, a multiply-add and the load -- no branch.  Idle lanes re-read piece 0.
+  const int pc = (lane & 31) < 25 ? (lane & 31) : 0;  // piece of the record
+  const bool second = lane >= 32;                     // ... of the pair's second task
+  const bool from_a = pc < 12;
+  const int64_t ydelta = (int64_t)((uintptr_t)Y - (uintptr_t)J) >> 3;  // (signed: Y may lie below J)
+  const int64_t mul = pc < 22 ? 24 : 6;
+  const int64_t add = pc < 12 ? 2 * pc : (pc < 17 ? 2 + 2 * (pc - 12) : (pc < 22 ? 14 + 2 * (pc - 17) : ydelta + 2 * (pc - 22)));
   for (int c0t = t_begin; c0t < t_end; c0t += 64) {
     const int nin = (t_end - c0t) < 64 ? (t_end - c0t) : 64;
     int my_oa = 0, my_ob = 0;
@@ -414,47 +433,40 @@ __device__ inline d4s schur_accumulate(int t_begin, int t_end, const int *__rest
       my_oa = task_a[c0t + lane];
       my_ob = task_b[c0t + lane];
     }
-    auto fetch = [&](int tq) -> double {  // element e of task tq of this chunk (0 when out of range; tq is wave-uniform)
-      if (tq >= nin) return 0.0;
-      const int oa = __builtin_amdgcn_readlane(my_oa, tq), ob = __builtin_amdgcn_readlane(my_ob, tq);
-      if (e < 24) return J[24 * (int64_t)oa + eoff];
-      if (e < 42) return J[24 * (int64_t)ob + eoff];
-      if (e < 48) return Y[6 * (int64_t)ob + eoff];
-      return 0.0;
+    auto issue = [&](int pr) {  // tasks 2 pr, 2 pr + 1 of this chunk (clamped to its last) -> slot pr % SCHUR_PF
+      int t0 = 2 * pr, t1 = 2 * pr + 1;
+      t0 = t0 < nin ? t0 : nin - 1;
+      t1 = t1 < nin ? t1 : nin - 1;
+      const int oa0 = __builtin_amdgcn_readlane(my_oa, t0), ob0 = __builtin_amdgcn_readlane(my_ob, t0);
+      const int oa1 = __builtin_amdgcn_readlane(my_oa, t1), ob1 = __builtin_amdgcn_readlane(my_ob, t1);
+      const int64_t o = second ? (from_a ? oa1 : ob1) : (from_a ? oa0 : ob0);
+      __builtin_amdgcn_global_load_lds(J + (mul * o + add), ring + (pr % SCHUR_PF) * SCHUR_SLOT, 16, 0, 0);
     };
-    double pf[SCHUR_PF][2];
+    const int npairs = (nin + 1) >> 1;
 #pragma unroll
-    for (int q = 0; q < SCHUR_PF; q++) {
-      pf[q][0] = fetch(2 * q);
-      pf[q][1] = fetch(2 * q + 1);
-    }
-    for (int tp = 0; tp < nin; tp += 2) {
-      const double ca_v = pf[0][0], cb_v = pf[0][1];
+    for (int q = 0; q < SCHUR_PF; q++) issue(q);
+    for (int pr0 = 0; pr0 < npairs; pr0 += SCHUR_PF) {
 #pragma unroll
-      for (int q = 0; q + 1 < SCHUR_PF; q++) {
-        pf[q][0] = pf[q + 1][0];
-        pf[q][1] = pf[q + 1][1];
+      for (int q = 0; q < SCHUR_PF; q++) {
+        const int pr = pr0 + q;
+        if (pr >= npairs) break;  // wave-uniform
+        // the oldest load of the ring has landed when at most SCHUR_PF - 1 are outstanding (vmcnt retires in order)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SCHUR_PF - 1) : "memory");
+        const double *sg = ring + q * SCHUR_SLOT + 64 * tl;
+        const bool on = (fr < 9) && (2 * pr + tl < nin);
+        const int fi = fr < 9 ? fr : 0;
+        const double a0 = sg[12 * al], a1 = sg[12 * al + 1], a2 = sg[12 * al + 2];
+        const double q0 = a0 * sg[44] + a1 * sg[46] + a2 * sg[48];
+        const double q1 = a0 * sg[45] + a1 * sg[47] + a2 * sg[49];
+        const double aop = on ? sg[12 * al + 3 + fi] : 0.0;
+        const double bop = on ? q0 * sg[25 + fi] + q1 * sg[35 + fi] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+        // the slot is free once its operands are in registers (the matrix instruction above has them): refill it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue(pr + SCHUR_PF);
       }
-      pf[SCHUR_PF - 1][0] = fetch(tp + 2 * SCHUR_PF);
-      pf[SCHUR_PF - 1][1] = fetch(tp + 2 * SCHUR_PF + 1);
-      if (e < 48) {
-        stage[0][e] = ca_v;
-        stage[1][e] = cb_v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const double *sg = stage[tl];
-      const bool on = (fr < 9) && (tp + tl < nin);
-      const int fi = fr < 9 ? fr : 0;
-      const double a0 = sg[12 * al], a1 = sg[12 * al + 1], a2 = sg[12 * al + 2];
-      const double q0 = a0 * sg[42] + a1 * sg[44] + a2 * sg[46];
-      const double q1 = a0 * sg[43] + a1 * sg[45] + a2 * sg[47];
-      const double aop = on ? sg[12 * al + 3 + fi] : 0.0;
-      const double bop = on ? q0 * sg[24 + fi] + q1 * sg[33 + fi] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
-      __builtin_amdgcn_wave_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped loads of the last trips: the ring is reused by the next chunk
   }
   return acc;
 }
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
                                                        const int *__restrict__ cam_of = nullptr) {
   // klist (per-rank ownership of S): the keys whose blocks touch the tile columns of the chunk being assembled; nkeys is
   // then the length of that list
-  __shared__ double stage[BLK / 64][2][48];
+  __shared__ __attribute__((aligned(16))) double ring[BLK / 64][SCHUR_RING];
   if (lam_dev) lambda *= lam_dev[0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4;
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
     const int64_t key = klist ? klist[kq] : kq;
     const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
     if (split_above > 0 && t_end - t_begin > split_above) continue;
-    const d4s acc = schur_accumulate(t_begin, t_end, task_a, task_b, J, Y, stage[wv]);
+    const d4s acc = schur_accumulate(t_begin, t_end, task_a, task_b, J, Y, ring[wv]);
     const int ca = key_ca[key], cb = key_cb[key];
     if (fr < 9) {
 #pragma unroll
@@ -517,11 +529,11 @@ __global__ __launch_bounds__(BLK) void k_schur_chunks(int64_t nchunks, const int
                                                        const int *__restrict__ task_a, const int *__restrict__ task_b,
                                                        const double *__restrict__ J, const double *__restrict__ Y,
                                                        double *__restrict__ partial) {
-  __shared__ double stage[BLK / 64][2][48];
+  __shared__ __attribute__((aligned(16))) double ring[BLK / 64][SCHUR_RING];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   for (int64_t c = (int64_t)blockIdx.x * (BLK / 64) + wv; c < nchunks; c += (int64_t)gridDim.x * (BLK / 64)) {
-    const d4s acc = schur_accumulate(chunk_t0[c], chunk_t1[c], task_a, task_b, J, Y, stage[wv]);
+    const d4s acc = schur_accumulate(chunk_t0[c], chunk_t1[c], task_a, task_b, J, Y, ring[wv]);
     if (fr < 9) {
 #pragma unroll
       for (int g = 0; g < 4; g++) {

@@ -111,6 +111,14 @@ def test_block_sparse_lookahead_same_bits_as_in_order(ba, gpu_ok, shuffle):
         m.close()
         return st
 
+    os.environ["BA_SPARSE_LOOKAHEAD_MIN"] = "1"  # fork however short the rest is (default: 256 tiles; restored below)
+    try:
+        _lookahead_checks(ba, step, run)
+    finally:
+        os.environ.pop("BA_SPARSE_LOOKAHEAD_MIN", None)
+
+
+def _lookahead_checks(ba, step, run):
     for ft in (None, np.float32):
         a1, a2, ha1, ha2, pat = _env("BA_SPARSE_S", "1", lambda: step(ft))
         b1, b2, hb1, hb2, _ = _env("BA_SPARSE_LOOKAHEAD", "0", lambda: _env("BA_SPARSE_S", "1", lambda: step(ft)))
