@@ -1251,7 +1251,10 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
                                                         const int *__restrict__ own_cols = nullptr,
                                                         const int64_t *__restrict__ own_pref = nullptr, int m0 = 0,
                                                         int m_end = 0, int ready_tiles = 1, const int *__restrict__ rows = nullptr,
-                                                        const T *__restrict__ Lp0 = nullptr, const T *__restrict__ Lp1 = nullptr) {
+                                                        const T *__restrict__ Lp0 = nullptr, const T *__restrict__ Lp1 = nullptr,
+                                                        const int2 *__restrict__ tlist = nullptr) {
+  // tlist (block-sparse S on several ranks): the tiles (i, j) of this launch, listed (the pattern's tiles of the pair's update
+  // in the tile columns this rank owns)
   BA_VT
   static_assert(MODE == 1, "only the pair update is a tile-per-workgroup kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -1264,7 +1267,10 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
     int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (t >= nblk) return;
     tsel = t;
-    if (OWN) {
+    if (tlist) {
+      i = tlist[t].x;
+      j = tlist[t].y;
+    } else if (OWN) {
       const int64_t tt = t + own_pref[m0];
       int lo = m0, hi = m_end;  // largest m with own_pref[m] <= tt
       while (hi - lo > 1) {
@@ -1319,11 +1325,12 @@ __global__ __launch_bounds__(256) void k_ldl_update_part(T *__restrict__ S, cons
 // A rank that received the panel V = L D of tile column k from its owner rebuilds L_ik = V_i D_k^-1 in its own copy of S
 // (rows i0..nt-1), with the owner's arithmetic (k_ldl_trsm_rs: xv * (1 / d)), so that every rank holds the same bits.
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_scale_panel(T *__restrict__ Lcol, const T *__restrict__ V, const T *__restrict__ D_k, int i0) {
+__global__ __launch_bounds__(256) void k_ldl_scale_panel(T *__restrict__ Lcol, const T *__restrict__ V, const T *__restrict__ D_k, int i0,
+                                                          const int *__restrict__ rows = nullptr) {
   // Lcol: where the L tiles of this tile column live, tile row i at Lcol + i NB^2 (a column of S is contiguous: S + (co[k] - k)
   // NB^2; with per-rank ownership of S: a panel buffer)
   BA_VT
-  const int i = i0 + blockIdx.x;
+  const int i = rows ? rows[blockIdx.x] : i0 + blockIdx.x;  // rows: the tile rows of the panel's pattern (block-sparse S)
   const T *Vi = V + (int64_t)i * NB * NB;
   T *Sik = Lcol + (int64_t)i * NB * NB;
   const int c2 = threadIdx.x & 63;  // this thread's column pair (2 c2, 2 c2 + 1), the same in every row it touches
@@ -1628,6 +1635,8 @@ void dense_ldl_free(DenseLDLT<T> *w) {
   if (w->prow) (void)hipFree(w->prow);
   if (w->lcol) (void)hipFree(w->lcol);
   if (w->lpair) (void)hipFree(w->lpair);
+  if (w->upd_ij) (void)hipFree(w->upd_ij);
+  if (w->own_tiles) (void)hipFree(w->own_tiles);
   if (w->hoist) (void)hipStreamDestroy(w->hoist);
   if (w->rest) (void)hipStreamDestroy(w->rest);
   if (w->ev_top) (void)hipEventDestroy(w->ev_top);
@@ -1846,24 +1855,26 @@ int dense_ldl_factor(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_p
 
 template <typename T>
 int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {
-  if (w->prow) (void)hipFree(w->prow);
-  if (w->lcol) (void)hipFree(w->lcol);
-  if (w->lpair) (void)hipFree(w->lpair);
+  for (void *q : {(void *)w->prow, (void *)w->lcol, (void *)w->lpair, (void *)w->upd_ij, (void *)w->own_tiles})
+    if (q) (void)hipFree(q);
   w->prow = w->lcol = w->lpair = nullptr;
+  w->upd_ij = w->own_tiles = nullptr;
   w->pat = pat;
   w->sparse = pat != nullptr;
   if (!pat) return BA_OK;
   {
     // Compressed storage: only the tiles of the pattern are allocated.  Column j (pair q = j / 2, k = 2q) stores the tile rows
     // j, k+1 (even j), U_q, in that order; the table behind the column offsets gives every (i, j) its position (tix).
+    // On several ranks (per-rank ownership) a rank stores the columns of ITS pairs only, one contiguous range of the
+    // owner-major order; the other columns get a negative offset.
     const int64_t nt = w->nt;
+    const int P = w->own_only ? w->world : 1, me = w->own_only ? w->rank : 0;
     std::vector<int64_t> tab((size_t)(1 + nt + nt * nt), BA_NO_TILE);
     tab[0] = nt;
     int64_t *co = tab.data() + 1, *rp = tab.data() + 1 + nt;
-    int64_t off = 0;
+    w->h_col_cnt.assign((size_t)nt, 0);
     for (int64_t j = 0; j < nt; j++) {
-      const int64_t q = j / 2, k = 2 * q;
-      co[j] = off;
+      const int64_t q = j / 2;
       int64_t pos = 0;
       rp[j * nt + j] = pos++;
       const int l0 = pat->prow_ptr[(size_t)q], l1 = pat->prow_ptr[(size_t)q + 1];
@@ -1871,11 +1882,56 @@ int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {
         const int64_t i = pat->prow[(size_t)l];  // [k+1] + U_q
         if (i > j) rp[i * nt + j] = pos++;
       }
-      (void)k;
-      off += pos;
+      w->h_col_cnt[(size_t)j] = pos;
+    }
+    w->own_range.assign((size_t)P + 1, 0);
+    int64_t run = 0;
+    for (int r = 0; r < P; r++) {
+      w->own_range[(size_t)r] = run;
+      for (int64_t j = 0; j < nt; j++)
+        if ((j / 2) % P == r) {
+          if (r == me) co[j] = run;  // (made rank-local below)
+          run += w->h_col_cnt[(size_t)j];
+        }
+    }
+    w->own_range[(size_t)P] = run;
+    const int64_t base = w->own_range[(size_t)me];
+    for (int64_t j = 0; j < nt; j++)
+      if (co[j] >= 0) co[j] -= base;
+    w->s_tiles = std::max<int64_t>(1, w->own_range[(size_t)me + 1] - base);
+    if (w->own_only) {
+      // the running tile counts of the owned columns (k_ldl_update's OWN mode is not used with a pattern; the column scaling
+      // and the chunked assembly are), the stored tiles in storage order, and the update lists per pair
+      w->h_own_pref.assign(1, 0);
+      std::vector<int2> tiles;
+      for (int j : w->h_own_cols) {
+        w->h_own_pref.push_back(w->h_own_pref.back() + w->h_col_cnt[(size_t)j]);
+        const int64_t q = j / 2;
+        tiles.push_back(make_int2(j, j));
+        for (int l = pat->prow_ptr[(size_t)q]; l < pat->prow_ptr[(size_t)q + 1]; l++)
+          if (pat->prow[(size_t)l] > j) tiles.push_back(make_int2(pat->prow[(size_t)l], j));
+      }
+      BA_HIP_CHECK(hipMemcpy(w->own_pref, w->h_own_pref.data(), w->h_own_pref.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+      BA_HIP_CHECK(hipMalloc((void **)&w->own_tiles, (tiles.size() + 1) * sizeof(int2)));
+      if (!tiles.empty()) BA_HIP_CHECK(hipMemcpy(w->own_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
+      std::vector<int2> upd;
+      const int npairs = (int)((nt + 1) / 2);
+      w->h_upd_ptr.assign(1, 0);
+      w->h_upd_lead.assign((size_t)npairs, 0);
+      for (int q = 0; q < npairs; q++) {
+        const int k = 2 * q, l0 = pat->prow_ptr[(size_t)q], l1 = pat->prow_ptr[(size_t)q + 1];
+        for (int a = l0 + 1; a < l1; a++) {  // U_q (the list starts with tile row k+1)
+          const int j = pat->prow[(size_t)a];
+          if ((j / 2) % P != me) continue;
+          for (int c = a; c < l1; c++) upd.push_back(make_int2(pat->prow[(size_t)c], j));
+          if (j < k + 4) w->h_upd_lead[(size_t)q] = (int)upd.size() - w->h_upd_ptr.back();
+        }
+        w->h_upd_ptr.push_back((int)upd.size());
+      }
+      BA_HIP_CHECK(hipMalloc((void **)&w->upd_ij, (upd.size() + 1) * sizeof(int2)));
+      if (!upd.empty()) BA_HIP_CHECK(hipMemcpy(w->upd_ij, upd.data(), upd.size() * sizeof(int2), hipMemcpyHostToDevice));
     }
     w->h_col_tab.swap(tab);
-    w->s_tiles = off;
     if (w->col_tab) (void)hipFree(w->col_tab);
     w->col_tab = nullptr;
     BA_HIP_CHECK(hipMalloc((void **)&w->col_tab, w->h_col_tab.size() * sizeof(int64_t)));
@@ -2045,9 +2101,47 @@ static int launch_pair_owned(ba_problem *p, DenseLDLT<T> *w, int k, const T *V0,
   return BA_OK;
 }
 
+// the tiles [from, to) of pair q's update list (block-sparse S on several ranks: the pattern's tiles in this rank's columns)
+template <typename T>
+static int launch_pair_list(ba_problem *p, DenseLDLT<T> *w, int q, const T *V0, const T *V1, hipStream_t st, int from, int to) {
+  const int nblk = to - from;
+  if (nblk <= 0) return BA_OK;
+  ProfScope ps(p, PC_LDL_UPDATE, st);
+  hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S, w->col_off, V0, V1,
+                     2 * q, 2 * q + 2, (int)w->nt, nblk, (int *)nullptr, (const int *)nullptr, (const int64_t *)nullptr, 0, 0, 1,
+                     (const int *)nullptr, (const T *)(w->Lb + (V0 - w->V)), (const T *)(w->Lb + (V1 - w->V)),
+                     (const int2 *)(w->upd_ij + w->h_upd_ptr[(size_t)q] + from));
+  return BA_OK;
+}
+
 // the panel chain of pair (k, k+1) on its owner (dense_ldl_factor's in-order chain, no right-hand side)
 template <typename T>
 static int dist_chain(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *V1, hipStream_t st) {
+  if (w->sparse) {  // over the pattern's row lists, as dense_ldl_factor_sparse
+    const TilePattern *pat = w->pat;
+    const int q = k / 2, l0 = pat->prow_ptr[(size_t)q], c1 = pat->prow_ptr[(size_t)q + 1] - l0, c2 = c1 > 0 ? c1 - 1 : 0;
+    launch_diag(p, w, k, st);
+    if (c1 > 0) {
+      {
+        ProfScope ps(p, PC_LDL_TRSM, st);
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+                           w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, V0, k, (T *)nullptr, (T *)nullptr, w->prow + l0);
+      }
+      {
+        ProfScope ps(p, PC_LDL_SYRK, st);
+        hipLaunchKernelGGL(k_ldl_col_rs<T>, dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, V0, k, w->prow + l0);
+      }
+      launch_diag(p, w, k + 1, st);
+      if (c2 > 0) {
+        ProfScope ps(p, PC_LDL_TRSM, st);
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * c2), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+                           w->Linv + (int64_t)(k + 1) * NB * NB, w->D + (int64_t)(k + 1) * NB, V1, k + 1, (T *)nullptr, (T *)nullptr,
+                           w->prow + l0 + 1);
+      }
+    }
+    BA_HIP_CHECK(hipGetLastError());
+    return BA_OK;
+  }
   launch_diag(p, w, k, st);
   launch_trsm(p, w, k, V0, (T *)nullptr, st);
   if (k + 1 < (int)w->nt) {
@@ -2065,6 +2159,32 @@ template <typename T>
 static int dist_transfer(ba_problem *p, DenseLDLT<T> *w, int k, T *V0, T *V1, int owner, hipStream_t st) {
   const int nt = (int)w->nt;
   const bool two = k + 1 < nt;
+  if (w->sparse) {  // the pattern's tile rows only: one broadcast per run of consecutive rows (a band: one run per panel)
+    const TilePattern *pat = w->pat;
+    const int q = k / 2, l0 = pat->prow_ptr[(size_t)q], c1 = pat->prow_ptr[(size_t)q + 1] - l0, c2 = c1 > 0 ? c1 - 1 : 0;
+    BA_CHECK(comm_group_begin(p));
+    int rc = BA_OK;
+    auto bcast_rows = [&](T *V, int first, int cnt) {
+      for (int a = 0; a < cnt && rc == BA_OK;) {
+        int b = a + 1;
+        while (b < cnt && pat->prow[(size_t)(first + b)] == pat->prow[(size_t)(first + b - 1)] + 1) b++;
+        rc = comm_bcast(p, V + (int64_t)pat->prow[(size_t)(first + a)] * NB * NB, (int64_t)(b - a) * NB * NB * sizeof(T), owner, st);
+        a = b;
+      }
+    };
+    bcast_rows(V0, l0, c1);
+    if (two) bcast_rows(V1, l0 + 1, c2);
+    if (rc == BA_OK) rc = comm_bcast(p, w->Linv + (int64_t)k * NB * NB, (int64_t)(two ? 2 : 1) * NB * NB * sizeof(T), owner, st);
+    if (rc == BA_OK) rc = comm_bcast(p, w->D + (int64_t)k * NB, (int64_t)(two ? 2 : 1) * NB * sizeof(T), owner, st);
+    BA_CHECK(comm_group_end(p));
+    BA_CHECK(rc);
+    T *L0 = w->Lb + (V0 - w->V), *L1 = w->Lb + (V1 - w->V);
+    if (c1 > 0) hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(c1), dim3(256), 0, st, L0, V0, w->D + (int64_t)k * NB, 0, w->prow + l0);
+    if (two && c2 > 0)
+      hipLaunchKernelGGL(k_ldl_scale_panel<T>, dim3(c2), dim3(256), 0, st, L1, V1, w->D + (int64_t)(k + 1) * NB, 0, w->prow + l0 + 1);
+    BA_HIP_CHECK(hipGetLastError());
+    return BA_OK;
+  }
   const int rows0 = nt - k - 1, rows1 = nt - k - 2;  // tile rows below the diagonal tile of column k / k + 1
   BA_CHECK(comm_group_begin(p));
   int rc = BA_OK;
@@ -2103,6 +2223,17 @@ static int dist_forward_pair(DenseLDLT<T> *w, int k, T *V0, T *V1, T *d_b, hipSt
   if (!d_b) return BA_OK;
   const int nt = (int)w->nt;
   T *y = w->D + (int64_t)nt * NB;
+  if (w->sparse) {
+    const TilePattern *pat = w->pat;
+    const int q = k / 2, l0 = pat->prow_ptr[(size_t)q], c1 = pat->prow_ptr[(size_t)q + 1] - l0, c2 = c1 > 0 ? c1 - 1 : 0;
+    hipLaunchKernelGGL(k_fwd_step<T>, dim3(1 + c1), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k, (const int *)(w->prow + l0),
+                       (const T *)(w->Lb + (V0 - w->V)));
+    if (k + 1 < nt)
+      hipLaunchKernelGGL(k_fwd_step<T>, dim3(1 + c2), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k + 1,
+                         (const int *)(w->prow + l0 + 1), (const T *)(w->Lb + (V1 - w->V)));
+    BA_HIP_CHECK(hipGetLastError());
+    return BA_OK;
+  }
   hipLaunchKernelGGL(k_fwd_step<T>, dim3(nt - k), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k, (const int *)nullptr,
                      (const T *)(w->Lb + (V0 - w->V)));
   if (k + 1 < nt)
@@ -2146,6 +2277,24 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, T *d_b
   auto own_from = [&](int base) {  // index of the first owned tile column >= base
     return (int)(std::lower_bound(w->h_own_cols.begin(), w->h_own_cols.end(), base) - w->h_own_cols.begin());
   };
+  if (w->sparse && !w->own_only) {
+    ba_set_error("dense_ldl_factor_dist: a tile pattern needs per-rank ownership of S");
+    return BA_ERR_ARG;
+  }
+  // pair q's update of this rank's tile columns: `part` 0 = all of it, 1 = the next pair's own two columns only (when they
+  // are this rank's), 2 = what remains after part 1
+  auto update_mine = [&](int q, const T *V0, const T *V1, int part, bool next_mine) -> int {
+    const int k = 2 * q;
+    if (w->sparse) {
+      const int n = w->h_upd_ptr[(size_t)q + 1] - w->h_upd_ptr[(size_t)q], lead = next_mine ? w->h_upd_lead[(size_t)q] : 0;
+      if (part == 1) return launch_pair_list(p, w, q, V0, V1, st, 0, lead);
+      return launch_pair_list(p, w, q, V0, V1, st, part == 2 ? lead : 0, n);
+    }
+    int m0 = own_from(k + 2);
+    const int lead = next_mine ? ((k + 3 < nt) ? 2 : 1) : 0;
+    if (part == 1) return launch_pair_owned(p, w, k, V0, V1, st, m0, m0 + lead);
+    return launch_pair_owned(p, w, k, V0, V1, st, part == 2 ? m0 + lead : m0, M);
+  };
   if (la_off || p->prof_on) {  // (per-kernel profiling times one launch at a time: nothing could overlap)
     for (int k = 0, q = 0; k < nt; k += 2, q++) {
       T *V0 = Vs[q & 1][0], *V1 = Vs[q & 1][1];
@@ -2154,7 +2303,7 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, T *d_b
       BA_CHECK(dist_transfer(p, w, k, V0, V1, owner, st));
       BA_CHECK(dist_forward_pair(w, k, V0, V1, d_b, st));
       if (k + 2 >= nt) break;
-      BA_CHECK(launch_pair_owned(p, w, k, V0, V1, st, own_from(k + 2), M));
+      BA_CHECK(update_mine(q, V0, V1, 0, false));
     }
   } else {
     hipStream_t cs = w->hoist;  // transfer stream
@@ -2174,15 +2323,12 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, T *d_b
       BA_CHECK(dist_forward_pair(w, k, V0, V1, d_b, st));  // (ahead of update q, whose event frees this buffer for transfer q+2)
       if (k + 2 >= nt) break;
       const bool next_mine = (q + 1) % P == me;
-      int m0 = own_from(k + 2);
       if (next_mine) {  // tile columns k+2 [, k+3] are mine and come first in the owned list
-        const int lead = (k + 3 < nt) ? 2 : 1;
-        BA_CHECK(launch_pair_owned(p, w, k, V0, V1, st, m0, m0 + lead));
+        BA_CHECK(update_mine(q, V0, V1, 1, true));
         BA_CHECK(dist_chain(p, w, k + 2, N0, N1, st));
         BA_HIP_CHECK(hipEventRecord(w->ev_dchain, st));
-        m0 += lead;
       }
-      BA_CHECK(launch_pair_owned(p, w, k, V0, V1, st, m0, M));
+      BA_CHECK(update_mine(q, V0, V1, 2, next_mine));
       BA_HIP_CHECK(hipEventRecord(w->ev_upd[q & 1], st));
       if (q >= 1) BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_upd[(q + 1) & 1], 0));  // update q-1 has read Vs[(q+1)&1]
       if (next_mine) BA_HIP_CHECK(hipStreamWaitEvent(cs, w->ev_dchain, 0));
@@ -2207,10 +2353,11 @@ int dense_ldl_factor_dist(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, T *d_b
 // rode along with the panels, dist_forward_pair.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_bwd_col_part(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ x,
-                                                       T *__restrict__ part, int k, int nt) {
-  // block b: tile row i = k + 2 + b / 2 of column c = k + (b & 1):  part[(c - k) nt + i][:] = L_ic' x_i
+                                                       T *__restrict__ part, int k, int nt, const int *__restrict__ rows = nullptr) {
+  // block b: tile row i = k + 2 + b / 2 (rows: the b / 2-th tile row of the pair's pattern) of column c = k + (b & 1):
+  // part[(c - k) nt + i][:] = L_ic' x_i
   __shared__ T xi[NB], red[2][NB];
-  const int c = k + (blockIdx.x & 1), i = k + 2 + (blockIdx.x >> 1);
+  const int c = k + (blockIdx.x & 1), i = rows ? rows[blockIdx.x >> 1] : k + 2 + (blockIdx.x >> 1);
   const int tid = threadIdx.x, col = tid & (NB - 1), half = tid >> 7;
   if (tid < NB) xi[tid] = x[(int64_t)i * NB + tid];
   __syncthreads();
@@ -2225,7 +2372,9 @@ __global__ __launch_bounds__(256) void k_bwd_col_part(const T *__restrict__ S, c
 template <typename T>
 __global__ __launch_bounds__(256) void k_bwd_col_final(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
                                                         const T *__restrict__ D, const T *__restrict__ y, const T *__restrict__ part,
-                                                        T *__restrict__ x, int k, int nt) {
+                                                        T *__restrict__ x, int k, int nt, const int *__restrict__ rows = nullptr,
+                                                        int nrows = 0) {
+  // rows / nrows: the tile rows below the pair that its pattern holds (block-sparse S); null: k + 2 .. nt - 1
   __shared__ T z[NB], xk1[NB], red[2][NB];
   const int tid = threadIdx.x, col = tid & (NB - 1), half = tid >> 7;
   const bool two = k + 1 < nt;
@@ -2237,7 +2386,10 @@ __global__ __launch_bounds__(256) void k_bwd_col_final(const T *__restrict__ S, 
   if (two) {  // x_{k+1} = Linv_{k+1}' (y_{k+1} / D_{k+1} - sum_{i > k+1} L_{i,k+1}' x_i)
     if (tid < NB) {
       T s = 0;
-      for (int i = k + 2; i < nt; i++) s += part[((int64_t)nt + i) * NB + tid];
+      if (rows)
+        for (int a = 0; a < nrows; a++) s += part[((int64_t)nt + rows[a]) * NB + tid];
+      else
+        for (int i = k + 2; i < nt; i++) s += part[((int64_t)nt + i) * NB + tid];
       z[tid] = y[(int64_t)(k + 1) * NB + tid] / D[(int64_t)(k + 1) * NB + tid] - s;
     }
     __syncthreads();
@@ -2253,7 +2405,10 @@ __global__ __launch_bounds__(256) void k_bwd_col_final(const T *__restrict__ S, 
   }
   if (tid < NB) {
     T s = two ? red[0][tid] + red[1][tid] : (T)0;
-    for (int i = k + 2; i < nt; i++) s += part[(int64_t)i * NB + tid];
+    if (rows)
+      for (int a = 0; a < nrows; a++) s += part[(int64_t)rows[a] * NB + tid];
+    else
+      for (int i = k + 2; i < nt; i++) s += part[(int64_t)i * NB + tid];
     z[tid] = y[(int64_t)k * NB + tid] / D[(int64_t)k * NB + tid] - s;
   }
   __syncthreads();
@@ -2270,7 +2425,15 @@ static int dense_ldl_bwd_dist(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_
   for (int k = last; k >= 0; k -= 2) {
     const int owner = (k / 2) % P;
     const bool two = k + 1 < nt;
-    if (owner == me) {
+    if (owner == me && w->sparse) {  // the pair's pattern rows only
+      const TilePattern *pat = w->pat;
+      const int q = k / 2, l0 = pat->prow_ptr[(size_t)q], c1 = pat->prow_ptr[(size_t)q + 1] - l0, c2 = c1 > 0 ? c1 - 1 : 0;
+      if (c2 > 0)
+        hipLaunchKernelGGL(k_bwd_col_part<T>, dim3(2 * c2), dim3(256), 0, st, w->S, w->col_off, d_b, w->bpart, k, nt, (const int *)(w->prow + l0 + 1));
+      hipLaunchKernelGGL(k_bwd_col_final<T>, dim3(1), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, w->bpart, d_b, k, nt,
+                         (const int *)(w->prow + l0 + 1), c2);
+      BA_HIP_CHECK(hipGetLastError());
+    } else if (owner == me) {
       const int below = nt - k - 2;  // tile rows below the pair
       if (below > 0)
         hipLaunchKernelGGL(k_bwd_col_part<T>, dim3(2 * below), dim3(256), 0, st, w->S, w->col_off, d_b, w->bpart, k, nt);

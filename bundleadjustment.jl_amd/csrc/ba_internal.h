@@ -113,6 +113,13 @@ struct DenseLDLT {  // workspace of the blocked LDL^T in scalar type T, n = 9*nc
   bool sparse = false;
   const TilePattern *pat = nullptr;
   int *prow = nullptr, *lcol = nullptr, *lpair = nullptr;
+  // ... on several ranks (per-rank ownership of the PATTERN's tile columns): tiles stored per tile column, the (i, j) of every
+  // tile this rank stores in storage order (column scaling), and per tile column pair q the tiles (i, j) -- both in U_q, j
+  // owned by this rank, sorted by (j, i) -- its trailing update touches here; the first h_upd_lead[q] of them lie in the next
+  // pair's own tile columns (look-ahead of the distributed factorisation)
+  std::vector<int64_t> h_col_cnt;
+  std::vector<int> h_upd_ptr, h_upd_lead;
+  int2 *upd_ij = nullptr, *own_tiles = nullptr;
   hipEvent_t ev_dtop = nullptr, ev_dchain = nullptr;  // distributed factorisation: fork behind the reduce of S, end of the owner's panel chain
 };
 typedef DenseLDLT<double> DenseLDL;

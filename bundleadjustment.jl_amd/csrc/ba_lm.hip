@@ -351,6 +351,10 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
   const int64_t nt = l.nt;
   const int P = l.world;
   const SchurTasks &T = w->tasks;
+  // block-sparse S: a tile column holds the pattern's tiles only (h_col_cnt) and the chunk tables are compressed like the
+  // workspace's own (head nt, column offsets, the shared nt x nt row positions)
+  const bool sparse = w->use_pattern;
+  auto col_tiles = [&](int64_t j) { return sparse ? l.h_col_cnt[(size_t)j] : nt - j; };
   std::vector<int> col_chunk((size_t)nt, -1);
   std::vector<std::vector<int64_t>> cco;
   w->chunks.clear();
@@ -375,7 +379,7 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
     };
     for (int64_t j = 0; j < nt; j++) {
       if ((j / 2) % P != r) continue;
-      const int64_t colt = nt - j;
+      const int64_t colt = col_tiles(j);
       if (c.ntiles > 0 && c.ntiles + colt > target) flush();
       table[(size_t)j] = local - c.t0;  // offset of tile (j, j) inside the chunk's destination buffer
       col_chunk[(size_t)j] = (int)w->chunks.size();
@@ -400,9 +404,13 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
   }
   for (size_t c = 0; c < nc; c++) {
     SchurChunk &ch = w->chunks[c];
-    {  // (tix reads the head of a table one entry before its pointer: 0 = dense columns)
-      std::vector<int64_t> with_head(cco[c].size() + 1, 0);
+    {  // (tix reads the head of a table one entry before its pointer: 0 = dense columns, nt = compressed ones)
+      std::vector<int64_t> with_head(cco[c].size() + 1 + (sparse ? (size_t)(nt * nt) : 0), 0);
       std::copy(cco[c].begin(), cco[c].end(), with_head.begin() + 1);
+      if (sparse) {
+        with_head[0] = nt;
+        std::copy(l.h_col_tab.begin() + 1 + nt, l.h_col_tab.end(), with_head.begin() + 1 + nt);
+      }
       BA_CHECK(upload_vec(&ch.cco_alloc, with_head));
       ch.cco = ch.cco_alloc + 1;
     }
@@ -413,6 +421,69 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
   }
   BA_HIP_CHECK(hipMalloc((void **)&w->stage, (size_t)std::max<int64_t>(1, w->stage_tiles) * NB * NB * sizeof(double)));
   return BA_OK;
+}
+
+// OR of a flag array over the ranks (set-up only): as doubles through the all-reduce the transport has
+static int allreduce_flags(ba_problem *p, std::vector<unsigned char> *flags) {
+  if (!p->comm.active() || flags->empty()) return BA_OK;
+  std::vector<double> h(flags->begin(), flags->end());
+  double *d = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&d, h.size() * sizeof(double)));
+  BA_HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  int rc = comm_allreduce(p, d, (int64_t)h.size(), p->stream);
+  if (rc == BA_OK) {
+    hipError_t e = hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) {
+      ba_set_error("allreduce_flags: %s", hipGetErrorString(e));
+      rc = BA_ERR_HIP;
+    }
+  }
+  (void)hipFree(d);
+  BA_CHECK(rc);
+  for (size_t i = 0; i < h.size(); i++) (*flags)[i] = h[i] != 0.0;
+  return BA_OK;
+}
+
+// OR of the camera graph over the ranks: a rank's observations only show the camera pairs ITS points connect, the ordering
+// must be that of the whole problem and the same on every rank.  The bit rows travel as counts, eight 6-bit fields per
+// double (a field holds at most `world` <= 63), in slices of at most 128 MB.
+static int allreduce_cam_graph(ba_problem *p, CamGraph *g) {
+  if (!p->comm.active() || g->bits.empty()) return BA_OK;
+  const size_t nwords = g->bits.size(), ndbl = nwords * 8;
+  const size_t slice = std::min<size_t>(ndbl, (size_t)16 << 20);
+  std::vector<double> h(slice);
+  double *d = nullptr;
+  BA_HIP_CHECK(hipMalloc((void **)&d, slice * sizeof(double)));
+  int rc = BA_OK;
+  for (size_t off = 0; off < ndbl && rc == BA_OK; off += slice) {
+    const size_t cnt = std::min(slice, ndbl - off);
+    for (size_t i = 0; i < cnt; i++) {  // double off + i: byte ((off + i) & 7) of word (off + i) / 8
+      const uint64_t byte = (g->bits[(off + i) >> 3] >> (8 * ((off + i) & 7))) & 0xff;
+      uint64_t packed = 0;
+      for (int b = 0; b < 8; b++) packed |= ((byte >> b) & 1) << (6 * b);
+      h[i] = (double)packed;
+    }
+    hipError_t e = hipMemcpyAsync(d, h.data(), cnt * sizeof(double), hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) rc = comm_allreduce(p, d, (int64_t)cnt, p->stream);
+    if (e == hipSuccess && rc == BA_OK) e = hipMemcpyAsync(h.data(), d, cnt * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess && rc == BA_OK) e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) {
+      ba_set_error("allreduce_cam_graph: %s", hipGetErrorString(e));
+      rc = BA_ERR_HIP;
+    }
+    if (rc != BA_OK) break;
+    for (size_t i = 0; i < cnt; i++) {
+      const uint64_t packed = (uint64_t)h[i];
+      uint64_t byte = 0;
+      for (int b = 0; b < 8; b++) byte |= (uint64_t)(((packed >> (6 * b)) & 63) != 0) << b;
+      uint64_t &word = g->bits[(off + i) >> 3];
+      const int sh = 8 * (int)((off + i) & 7);
+      word = (word & ~((uint64_t)0xff << sh)) | (byte << sh);
+    }
+  }
+  (void)hipFree(d);
+  return rc;
 }
 
 // Fill-reducing ordering of the cameras inside the reduced camera system -- what `perm` asks of the reference's sparse
@@ -429,9 +500,13 @@ static int order_cameras(ba_problem *p, LMWorkFull *w, std::vector<int> *pos_out
     method = e[0] == 'n' ? BA_ORDER_NATURAL : (e[0] == 'm' ? BA_ORDER_METIS : BA_ORDER_AMD);
   }
   const int64_t n = p->ncams;
-  if (method == BA_ORDER_NATURAL || n < 2 * (NB / 9) || p->comm.active()) return BA_OK;  // (fewer cameras than two tiles hold: dense anyway)
+  // (fewer cameras than two tiles hold: dense anyway; several ranks: with per-rank ownership of S only, and at most 63 ranks
+  // -- the graph's bits are summed as 6-bit counts)
+  if (method == BA_ORDER_NATURAL || n < 2 * (NB / 9)) return BA_OK;
+  if (p->comm.active() && (!w->ldl.own_only || p->comm.world > 63)) return BA_OK;
   CamGraph g;
   cam_graph_build(n, p->npnts, p->h_pt_ptr.data(), p->h_pt_obs.data(), p->h_cam0.data(), &g);
+  BA_CHECK(allreduce_cam_graph(p, &g));
   // more than half of all camera pairs share points: S is dense at tile granularity whatever the order
   if ((double)g.edges() > 0.25 * (double)n * (double)(n - 1)) return BA_OK;
   std::vector<int> perm;
@@ -459,12 +534,14 @@ static int ensure_dense(ba_problem *p, LMWorkFull *w) {
   // Block-sparse reduced camera system (one GPU): symbolic factorisation of the tile occupancy; the list schedule is used
   // when the pattern's trailing updates are at most 60 % of the dense factorisation's (BA_SPARSE_S=1 / 0 forces it on /
   // off).  Every camera pair sharing points (the default synthetic generator, small problems) gives flop_fill = 1: dense.
+  // several ranks: a rank's keys only show the tiles ITS observations touch; the pattern is that of the sum
+  if (dist_factor_on(p)) BA_CHECK(allreduce_flags(p, &w->tasks.tile_occ));
   tile_pattern_build(w->ldl.nt, w->tasks.tile_occ, &w->pattern);
   w->tasks.tile_occ.clear();
   w->tasks.tile_occ.shrink_to_fit();
   const char *e = getenv("BA_SPARSE_S");
   const bool want = e ? e[0] != '0' : (w->pattern.flop_fill <= 0.6 && w->ldl.nt >= 8);
-  w->use_pattern = want && !p->comm.active();
+  w->use_pattern = want && (!p->comm.active() || w->ldl.own_only);  // (several ranks: with per-rank ownership of S only)
   if (w->use_pattern) BA_CHECK(dense_ldl_use_pattern(&w->ldl, &w->pattern));  // (compressed layout: before S is allocated)
   BA_CHECK(dense_ldl_alloc_S(&w->ldl));
   if (w->ldl.own_only) BA_CHECK(build_chunks(p, w));
@@ -732,7 +809,10 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   }
   if (normalize != 0) {  // :J / :A column scaling of the camera system from the GLOBAL diagonal (refresh_linearisation)
     BA_CHECK(launch_cam_scale(p, w->hdiag, normalize == 2 ? lambda : 0.0, w->colscale, st, d_lambda, w->tasks.pos));
-    if (w->ldl.own_only)
+    if (w->ldl.own_only && w->use_pattern)
+      BA_CHECK(launch_scale_S_list(p, w->n, w->colscale, w->ldl.S, w->ldl.own_tiles,
+                                   w->ldl.own_range[(size_t)w->ldl.rank + 1] - w->ldl.own_range[(size_t)w->ldl.rank], st));
+    else if (w->ldl.own_only)
       BA_CHECK(launch_scale_S_own(p, w->n, w->colscale, w->ldl.S, w->ldl.col_off, w->ldl.own_cols, w->ldl.own_pref,
                                   (int)w->ldl.h_own_cols.size(), w->ldl.own_range[(size_t)w->ldl.rank + 1] - w->ldl.own_range[(size_t)w->ldl.rank], st));
     else

@@ -110,6 +110,7 @@ int launch_schur_chunk(ba_problem *p, const SchurTasks *T, const SchurChunk *c, 
                        const double *d_lambda = nullptr, const double *d_damp = nullptr);
 int launch_scale_S_own(ba_problem *p, int64_t n, const double *d_dsc, double *d_S, const int64_t *d_col_off, const int *d_own_cols,
                        const int64_t *d_own_pref, int ncols, int64_t ntiles, hipStream_t st);
+int launch_scale_S_list(ba_problem *p, int64_t n, const double *d_dsc, double *d_S, const int2 *d_tiles, int64_t ntiles, hipStream_t st);
 int launch_schur_rhs(ba_problem *p, const double *d_J, const double *d_r, const double *d_u, double *d_rhs,
                      hipStream_t st, const int *d_cam_pnt = nullptr, const int *d_pos = nullptr /* block row of a camera */);
 int launch_gather_cams(ba_problem *p, const int *d_pos, const double *d_src, double *d_dst, hipStream_t st);

@@ -1348,6 +1348,24 @@ int launch_scale_S_own(ba_problem *p, int64_t n, const double *d_dsc, double *d_
   return BA_OK;
 }
 
+// the same over a list of stored tiles (block-sparse S with per-rank ownership): tile t of S is (tiles[t].x, tiles[t].y)
+__global__ __launch_bounds__(BLK) void k_scale_S_list(int64_t n, const double *__restrict__ dsc, double *__restrict__ S,
+                                                       const int2 *__restrict__ tiles) {
+  const int64_t t = blockIdx.x, ti = tiles[t].x, tj = tiles[t].y;
+  double *T = S + t * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += BLK) {
+    const int64_t r = ti * NB + (e >> 7), c = tj * NB + (e & (NB - 1));
+    const double dr = r < n ? dsc[r] : 1.0, dc = c < n ? dsc[c] : 1.0;
+    T[e] /= dr * dc;
+  }
+}
+int launch_scale_S_list(ba_problem *p, int64_t n, const double *d_dsc, double *d_S, const int2 *d_tiles, int64_t ntiles, hipStream_t st) {
+  if (ntiles <= 0) return BA_OK;
+  hipLaunchKernelGGL(k_scale_S_list, dim3((unsigned)ntiles), dim3(BLK), 0, st, n, d_dsc, d_S, d_tiles);
+  BA_HIP_CHECK(hipGetLastError());
+  return BA_OK;
+}
+
 int launch_hcc_diag(ba_problem *p, const double *d_Hcc, double *d_hdiag, hipStream_t st) {
   if (p->ncams == 0) return BA_OK;
   hipLaunchKernelGGL(k_hcc_diag, dim3(grid_for(9 * p->ncams, BLK)), dim3(BLK), 0, st, p->ncams, d_Hcc, d_hdiag);

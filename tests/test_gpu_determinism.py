@@ -325,6 +325,104 @@ def test_loopback_lookahead_same_bits_as_alternating(ba, loopback, ncams, npnts,
         R.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("irregular", [False, True])
+def test_loopback_block_sparse_on_several_ranks(ba, loopback, world, irregular):
+    """The list schedule of the block-sparse reduced camera system on 2 / 3 ranks of one process (per-rank ownership of the
+    PATTERN's tile columns, chunked assembly over pattern tiles, panel broadcast of pattern rows, list-driven updates and
+    sweeps): the one-rank step to 1e-9 (Float64) / 5e-3 (Float32 factorisation), the camera part bit-identical on every
+    rank, look-ahead = alternating bit for bit, and a rank holds at most 1.5 x its share of the PATTERN.  Problems: 520
+    cameras (n = 4680, 37 tile rows), cameras of a point within 14 % of the cameras -- a band -- and the same with the
+    cameras renumbered in whole groups (an irregular pattern: row lists with gaps, broadcasts in several runs); the pattern
+    of a rank's own observations differs from rank to rank, the handles agree on the pattern of the sum."""
+    p0 = ba.synthetic.make_problem(520, 5200, 26000, seed=12, locality=0.08 if irregular else 0.14)
+    if irregular:  # whole groups of 14 cameras (a tile's worth) shuffled inside windows of six groups
+        rng = np.random.default_rng(12)
+        ng = 520 // 14
+        gperm = np.arange(ng)
+        for g0 in range(0, ng, 6):
+            gperm[g0:g0 + 6] = rng.permutation(gperm[g0:g0 + 6])
+        sigma = np.arange(520)
+        for g in range(ng):
+            sigma[g * 14:(g + 1) * 14] = gperm[g] * 14 + np.arange(14)
+        p0, _ = ba.synthetic.shuffle_cameras(p0, sigma=sigma)
+    prob = p0
+    os.environ["BA_SPARSE_S"] = "1"
+    os.environ["BA_CAM_ORDER"] = "natural"  # (the numbering is the test's own: irregular on purpose)
+    try:
+        ref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob))
+        d_ref, half_ref, _ = ba.lm_step(ref, prob["x0"], 10.0)
+        d32_ref, _, _ = ba.lm_step(ref, prob["x0"], 10.0, facto_type=np.float32)
+        tf, ff, sparse_one = ba.schur_pattern(ref)
+        full_one, held_one, _ = ba.schur_memory(ref)
+        ref.close()
+        assert sparse_one and held_one < full_one
+        R = _Ranks(ba, loopback, prob, world, stage_mb=256)
+        try:
+            runs = {}
+            for tag, on in (("look-ahead", True), ("alternating", False)):
+                _set_lookahead(on)
+                d, cams, half = R.step(10.0)
+                e = rel_err(d, d_ref)
+                assert e <= 1e-9, f"{world} ranks, {tag}: |delta - delta_one_rank| / |delta_one_rank| = {e:.3e} (limit 1e-9)"
+                assert abs(half - half_ref) <= 1e-10 * half_ref
+                for r in range(1, world):
+                    rep = bits_report(cams[0], cams[r], f"{tag}: camera step of rank 0 vs rank {r}")
+                    assert not rep, rep
+                runs[tag] = cams[0]
+            rep = bits_report(runs["look-ahead"], runs["alternating"], "camera step, look-ahead vs alternating")
+            assert not rep, rep
+            _set_lookahead(True)
+            d32, cams32, _ = R.step(10.0, facto_type=np.float32)
+            e32 = rel_err(d32, d32_ref)
+            assert e32 <= 5e-3, f"{world} ranks, Float32 factor: relative step difference {e32:.3e} (limit 5e-3)"
+            held_sum = 0
+            for r, m in enumerate(R.models):
+                t, f, sp = ba.schur_pattern(m)
+                full, held, staging = ba.schur_memory(m)
+                assert sp and abs(t - tf) < 1e-12 and abs(f - ff) < 1e-12, f"rank {r}: pattern {t, f, sp} vs one rank {tf, ff}"
+                slack = 2 * 37  # one tile column pair
+                assert held <= held_one / world + slack, f"rank {r}: holds {held} tiles, pattern {held_one}, {world} ranks"
+                assert held + staging <= 1.5 * held_one / world + 2 * slack, f"rank {r}: {held} + {staging} tiles against 1.5 x {held_one} / {world}"
+                held_sum += held
+            assert held_sum == held_one, f"the ranks hold {held_sum} tiles together, the pattern has {held_one}"
+            print(f"{world} ranks, {'irregular' if irregular else 'band'}: pattern {held_one} of {full_one} tiles, per rank "
+                  f"{[ba.schur_memory(m)[1:] for m in R.models]}")
+        finally:
+            _set_lookahead(True)
+            R.close()
+    finally:
+        os.environ.pop("BA_SPARSE_S", None)
+        os.environ.pop("BA_CAM_ORDER", None)
+
+
+def test_loopback_camera_ordering_on_several_ranks(ba, loopback):
+    """A randomly numbered block-banded problem on 3 ranks: every rank sees only the camera pairs ITS points connect; the
+    camera graph is summed over the ranks before it is ordered, so every handle arrives at the sequence (and the pattern)
+    of the one-rank handle, takes the list schedule, and the step is the one-rank step."""
+    p0 = ba.synthetic.make_problem(520, 5200, 26000, seed=13, locality=0.12)
+    prob, _ = ba.synthetic.shuffle_cameras(p0, seed=6)
+    ref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob))
+    d_ref, half_ref, _ = ba.lm_step(ref, prob["x0"], 10.0)
+    pat_ref, (perm_ref, name_ref) = ba.schur_pattern(ref), ba.schur_ordering_used(ref)
+    ref.close()
+    assert pat_ref[2] and name_ref != "natural"
+    R = _Ranks(ba, loopback, prob, 3, stage_mb=256)
+    try:
+        d, cams, half = R.step(10.0)
+        e = rel_err(d, d_ref)
+        assert e <= 1e-9, f"3 ranks with a camera ordering: relative difference to the one-rank step {e:.3e}"
+        for r, m in enumerate(R.models):
+            perm, name = ba.schur_ordering_used(m)
+            assert np.array_equal(perm, perm_ref) and name == name_ref, f"rank {r}: sequence '{name}' differs from the one-rank handle's '{name_ref}'"
+            assert ba.schur_pattern(m) == pat_ref, f"rank {r}: pattern {ba.schur_pattern(m)} vs {pat_ref}"
+            if r:
+                rep = bits_report(cams[0], cams[r], f"camera step of rank 0 vs rank {r}")
+                assert not rep, rep
+    finally:
+        R.close()
+
+
 def test_loopback_lm_runs_equal_one_rank(ba, loopback):
     """Complete LM runs on 3 ranks of one process over the loopback transport (per-rank ownership of S, distributed
     factorisation and backward sweep, chunked assembly): lm.jl with and without column scaling -- the scaling uses the
