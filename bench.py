@@ -425,7 +425,7 @@ def main():
                                     "S_gib_held": held * 128 * 128 * 8 / 2 ** 30}
         if reducer is not None:
             out["comm"] = {"transport": "rccl (called from the library)" if args.backend == "nccl" else "hook over " + args.backend,
-                           "calls": reducer.calls, "bytes": reducer.bytes,
+                           "calls": reducer.calls, "bytes": reducer.bytes, "by_operation": reducer.stats_by_op(),
                            "ms_profiled_run": prof.get("allreduce", (None, 0))[0]}
         print(json.dumps(out))
     nlp.close()

@@ -44,7 +44,9 @@ class LMStats(C.Structure):
 LOG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                      C.c_double, C.c_int)
 COMM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
-COMM_ALLREDUCE_F64, COMM_REDUCE_F64, COMM_BCAST_BYTES, COMM_REDUCE_F32 = 0, 1, 2, 3
+COMM_ALLREDUCE_F64, COMM_REDUCE_F64, COMM_BCAST_BYTES, COMM_REDUCE_F32, COMM_REDUCE_SCATTER_F64, COMM_REDUCE_SCATTER_F32 = 0, 1, 2, 3, 4, 5
+COMM_OPS = 6
+COMM_OP_NAMES = ("allreduce_f64", "reduce_f64", "bcast_bytes", "reduce_f32", "reduce_scatter_f64", "reduce_scatter_f32")
 COMM_ID_BYTES = 128
 
 # every symbol include/ba_hip.h declares (tests check that the library exports all of them)
@@ -54,7 +56,7 @@ SYMBOLS = [
     "ba_jac_structure", "ba_jac_coord", "ba_jac_coord_f32", "ba_jtr", "ba_residual_dev", "ba_residual_f32_dev",
     "ba_jac_structure_dev", "ba_jac_coord_dev", "ba_jac_coord_f32_dev", "ba_jtr_dev", "ba_dev_malloc", "ba_dev_free",
     "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_memcpy_h2d_on", "ba_memcpy_d2h_on", "ba_synchronize", "ba_lm_solve", "ba_comm_get_unique_id", "ba_lm_set_comm_rccl",
-    "ba_lm_set_comm_hook", "ba_comm_stats", "ba_dist_layout",
+    "ba_lm_set_comm_hook", "ba_comm_stats", "ba_comm_stats_ops", "ba_dist_layout",
     "ba_lm_step", "ba_lm_step_f32", "ba_lm_step_pcg", "ba_lm_schur_pattern", "ba_lm_schur_memory", "ba_schur_ordering", "ba_lm_set_ordering", "ba_lm_schur_ordering", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
 ]
 
@@ -99,6 +101,7 @@ def lib():
     L.ba_lm_set_comm_rccl.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ba_lm_set_comm_hook.argtypes = [vp, C.c_int, C.c_int, COMM_CB, vp]
     L.ba_comm_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.ba_comm_stats_ops.argtypes = [vp, vp, vp]
     L.ba_dist_layout.argtypes = [i64, C.c_int, vp, vp]
     L.ba_lm_step.argtypes = [vp, vp, f64, vp, C.POINTER(f64), vp]
     L.ba_lm_step_f32.argtypes = [vp, vp, f64, vp, C.POINTER(f64), vp]

@@ -27,6 +27,7 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
 };
@@ -59,6 +60,7 @@ int rccl_load() {
   BA_SYM(AllReduce, "ncclAllReduce")
   BA_SYM(Reduce, "ncclReduce")
   BA_SYM(Broadcast, "ncclBroadcast")
+  BA_SYM(ReduceScatter, "ncclReduceScatter")
   BA_SYM(GroupStart, "ncclGroupStart")
   BA_SYM(GroupEnd, "ncclGroupEnd")
 #undef BA_SYM
@@ -92,6 +94,8 @@ int comm_allreduce(ba_problem *p, double *d_buf, int64_t count, hipStream_t st) 
   ProfScope ps(p, PC_COMM, st);
   c->calls++;
   c->bytes += 8 * count;
+  c->op_calls[BA_COMM_ALLREDUCE_F64]++;
+  c->op_bytes[BA_COMM_ALLREDUCE_F64] += 8 * count;
   if (c->hook) return hook_call(c, BA_COMM_ALLREDUCE_F64, d_buf, count, 0, st);
   BA_NCCL_CHECK(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)c->nccl, st));
   return BA_OK;
@@ -103,6 +107,8 @@ int comm_reduce(ba_problem *p, double *d_buf, int64_t count, int root, hipStream
   ProfScope ps(p, PC_COMM, st);
   c->calls++;
   c->bytes += 8 * count;
+  c->op_calls[BA_COMM_REDUCE_F64]++;
+  c->op_bytes[BA_COMM_REDUCE_F64] += 8 * count;
   if (c->hook) return hook_call(c, BA_COMM_REDUCE_F64, d_buf, count, root, st);
   BA_NCCL_CHECK(g_rccl.Reduce(d_buf, d_buf, (size_t)count, ncclFloat64, ncclSum, root, (ncclComm_t)c->nccl, st));
   return BA_OK;
@@ -114,6 +120,8 @@ int comm_reduce_f32(ba_problem *p, float *d_buf, int64_t count, int root, hipStr
   ProfScope ps(p, PC_COMM, st);
   c->calls++;
   c->bytes += 4 * count;
+  c->op_calls[BA_COMM_REDUCE_F32]++;
+  c->op_bytes[BA_COMM_REDUCE_F32] += 4 * count;
   if (c->hook) return hook_call(c, BA_COMM_REDUCE_F32, d_buf, count, root, st);
   BA_NCCL_CHECK(g_rccl.Reduce(d_buf, d_buf, (size_t)count, ncclFloat32, ncclSum, root, (ncclComm_t)c->nccl, st));
   return BA_OK;
@@ -125,8 +133,27 @@ int comm_bcast(ba_problem *p, void *d_buf, int64_t bytes, int root, hipStream_t 
   ProfScope ps(p, PC_COMM, st);
   c->calls++;
   c->bytes += bytes;
+  c->op_calls[BA_COMM_BCAST_BYTES]++;
+  c->op_bytes[BA_COMM_BCAST_BYTES] += bytes;
   if (c->hook) return hook_call(c, BA_COMM_BCAST_BYTES, d_buf, bytes, root, st);
   BA_NCCL_CHECK(g_rccl.Broadcast(d_buf, d_buf, (size_t)bytes, ncclUint8, root, (ncclComm_t)c->nccl, st));
+  return BA_OK;
+}
+
+int comm_reduce_scatter(ba_problem *p, void *d_buf, int64_t count, bool f32, hipStream_t st) {
+  BaComm *c = &p->comm;
+  if (!c->active() || count <= 0) return BA_OK;
+  ProfScope ps(p, PC_COMM, st);
+  const int op = f32 ? BA_COMM_REDUCE_SCATTER_F32 : BA_COMM_REDUCE_SCATTER_F64;
+  const int64_t esize = f32 ? 4 : 8, bytes = esize * count * c->world;
+  c->calls++;
+  c->bytes += bytes;
+  c->op_calls[op]++;
+  c->op_bytes[op] += bytes;
+  if (c->hook) return hook_call(c, op, d_buf, count, 0, st);
+  // in place: the receive buffer is this rank's own segment of the send buffer
+  BA_NCCL_CHECK(g_rccl.ReduceScatter(d_buf, (char *)d_buf + (int64_t)c->rank * count * esize, (size_t)count, f32 ? ncclFloat32 : ncclFloat64,
+                                     ncclSum, (ncclComm_t)c->nccl, st));
   return BA_OK;
 }
 
@@ -211,6 +238,15 @@ extern "C" int ba_comm_stats(ba_problem *p, int64_t *calls, int64_t *bytes) {
   if (!p) return BA_ERR_ARG;
   if (calls) *calls = p->comm.calls;
   if (bytes) *bytes = p->comm.bytes;
+  return BA_OK;
+}
+
+extern "C" int ba_comm_stats_ops(ba_problem *p, int64_t *calls, int64_t *bytes) {
+  if (!p) return BA_ERR_ARG;
+  for (int q = 0; q < BA_COMM_OPS; q++) {
+    if (calls) calls[q] = p->comm.op_calls[q];
+    if (bytes) bytes[q] = p->comm.op_bytes[q];
+  }
   return BA_OK;
 }
 

@@ -131,6 +131,7 @@ struct BaComm {
   void *hook_ctx = nullptr;
   void *nccl = nullptr;  // ncclComm_t
   int64_t calls = 0, bytes = 0;
+  int64_t op_calls[BA_COMM_OPS] = {}, op_bytes[BA_COMM_OPS] = {};
   bool active() const { return hook != nullptr || nccl != nullptr; }  // a 1-rank communicator still exercises the path
 };
 
@@ -231,6 +232,8 @@ int comm_allreduce(ba_problem *p, double *d_buf, int64_t count, hipStream_t st);
 int comm_reduce(ba_problem *p, double *d_buf, int64_t count, int root, hipStream_t st);  // sum lands on root only
 int comm_reduce_f32(ba_problem *p, float *d_buf, int64_t count, int root, hipStream_t st);
 int comm_bcast(ba_problem *p, void *d_buf, int64_t bytes, int root, hipStream_t st);
+// d_buf: world segments of `count` elements (Float64, or Float32 when f32); segment `rank` receives the sum, in place
+int comm_reduce_scatter(ba_problem *p, void *d_buf, int64_t count, bool f32, hipStream_t st);
 int comm_group_begin(ba_problem *p);  // RCCL: fuse the calls up to comm_group_end into one launch
 int comm_group_end(ba_problem *p);
 void comm_free(ba_problem *p);

@@ -195,7 +195,10 @@ struct LMWorkFull : LMWork {
   std::vector<SchurChunk> chunks;  // per-rank ownership of S: chunks of tile columns, assembled and reduced one by one
   double *stage = nullptr;         // the chunk being assembled for another owner (stage_tiles tiles)
   float *stage32 = nullptr;        // its Float32 copy when the reduce travels in Float32
-  int64_t stage_tiles = 0;
+  int64_t stage_tiles = 0;         // (reduce-scatter assembly: all the staging tiles, stage_bufs buffers of stage_tiles / stage_bufs)
+  bool assembly_rs = false;        // chunks are reduce-scattered (one segment per owner) instead of reduced onto one owner
+  int stage_bufs = 1;              // 2: chunk c+1 is assembled while chunk c travels (transfer stream)
+  hipEvent_t ev_stage_ready[2] = {nullptr, nullptr}, ev_stage_free[2] = {nullptr, nullptr};
   TilePattern pattern;       // tile pattern of S after the symbolic factorisation (ensure_dense)
   bool use_pattern = false;  // the block-sparse list schedule is in use on this handle
   // fill-reducing camera ordering of the reduced camera system (`perm` of the reference's solvers, src/lm.jl:84-88): the
@@ -346,7 +349,117 @@ static int lm_ensure(ba_problem *p) {
 // ever holds more of S than its own columns plus one chunk: <= 1.5 |S| / world (plus the panel buffers of the
 // factorisation).  A key's 9 x 9 block can straddle two tile columns: it is listed with both chunks and each stores the
 // elements that fall into its own columns (the offset table of the chunk marks the others).
+static int upload_chunk_tables(LMWorkFull *w, std::vector<std::vector<int64_t>> &cco, const std::vector<int> &col_chunk_of_col,
+                               bool sparse);
+
+// Reduce-scatter form of the chunked assembly (default; BA_ASSEMBLY=reduce keeps the chunk-onto-one-owner form).  A chunk
+// reduced onto ONE owner is a many-to-one transfer: over point-to-point xGMI it moves at one link's rate.  Here a chunk is
+// one slice of EVERY owner's tile columns -- `world` segments of `seg` tiles in the staging buffer, segment r a slice of rank
+// r's storage (whole tile columns; shorter slices zero-padded) -- and ONE in-place reduce-scatter delivers to every owner
+// its segment: all links of every GPU carry 1 / world of the chunk.  The owner then copies its segment into its tiles.  With
+// two staging buffers chunk c travels on the transfer stream while chunk c+1 is assembled on the main one.  Slices per
+// owner: as many as keep all staging within about half a rank's share of S (4 world with two buffers), never finer than a
+// tile column; when two buffers would not fit (small problems) there is one and the transfer is in line.
+static int build_chunks_rs(ba_problem *p, LMWorkFull *w) {
+  const DenseLDL &l = w->ldl;
+  const int64_t nt = l.nt;
+  const int P = l.world, me = l.rank;
+  const bool sparse = w->use_pattern;
+  auto col_tiles = [&](int64_t j) { return sparse ? l.h_col_cnt[(size_t)j] : nt - j; };
+  std::vector<int64_t> share((size_t)P, 0), local_off((size_t)nt, 0);
+  int64_t max_col = 1;
+  for (int r = 0; r < P; r++) {
+    int64_t run = 0;
+    for (int64_t j = 0; j < nt; j++)
+      if ((j / 2) % P == r) {
+        local_off[(size_t)j] = run;
+        run += col_tiles(j);
+        max_col = std::max(max_col, col_tiles(j));
+      }
+    share[(size_t)r] = run;
+  }
+  const int64_t max_share = *std::max_element(share.begin(), share.end());
+  const int64_t budget = std::max<int64_t>(max_share / 2, 1);  // all staging together
+  auto plan = [&](int nsl, std::vector<std::vector<std::pair<int64_t, int64_t>>> *slices, int64_t *seg_out) {
+    // per owner: its columns in order cut into nsl runs of about share / nsl tiles; slices[r][c] = (first column index in
+    // the owner's list, one past the last); seg = the longest run
+    slices->assign((size_t)P, {});
+    int64_t seg = 1;
+    for (int r = 0; r < P; r++) {
+      std::vector<int64_t> cols;
+      for (int64_t j = 0; j < nt; j++)
+        if ((j / 2) % P == r) cols.push_back(j);
+      // cumulative boundaries: slice c ends with the first column at which the running count reaches (c + 1) / nsl of the
+      // share, so no slice exceeds its even part by more than one column
+      size_t a = 0;
+      int64_t run = 0;
+      for (int c = 0; c < nsl; c++) {
+        const int64_t goal = (share[(size_t)r] * (c + 1) + nsl - 1) / nsl;
+        size_t b = a;
+        int64_t n = 0;
+        while (b < cols.size() && (run + n < goal || c == nsl - 1)) n += col_tiles(cols[b++]);
+        (*slices)[(size_t)r].push_back({(int64_t)a, (int64_t)b});
+        seg = std::max(seg, n);
+        run += n;
+        a = b;
+      }
+    }
+    *seg_out = seg;
+  };
+  std::vector<std::vector<std::pair<int64_t, int64_t>>> slices;
+  int64_t seg = 0;
+  int nsl = 4 * P, bufs = 2;
+  plan(nsl, &slices, &seg);
+  if (2 * P * seg > budget + 2 * nt) bufs = 1;  // two buffers do not fit (slices are whole tile columns): one, the transfer in line
+  w->assembly_rs = true;
+  w->stage_bufs = bufs;
+  w->stage_tiles = (int64_t)bufs * P * seg;
+  w->chunks.clear();
+  std::vector<std::vector<int64_t>> cco;
+  std::vector<int> col_chunk((size_t)nt, -1);
+  for (int c = 0; c < nsl; c++) {
+    SchurChunk ch;
+    ch.owner = -1;
+    ch.seg = seg;
+    ch.ntiles = (int64_t)P * seg;
+    std::vector<int64_t> table((size_t)nt, BA_NO_TILE);
+    bool any = false;
+    for (int r = 0; r < P; r++) {
+      std::vector<int64_t> cols;
+      for (int64_t j = 0; j < nt; j++)
+        if ((j / 2) % P == r) cols.push_back(j);
+      const auto sl = slices[(size_t)r][(size_t)c];
+      if (sl.first >= sl.second) continue;
+      any = true;
+      const int64_t t0 = local_off[(size_t)cols[(size_t)sl.first]];
+      int64_t n = 0;
+      for (int64_t a = sl.first; a < sl.second; a++) {
+        const int64_t j = cols[(size_t)a];
+        table[(size_t)j] = (int64_t)r * seg + (local_off[(size_t)j] - t0);
+        col_chunk[(size_t)j] = (int)w->chunks.size();
+        n += col_tiles(j);
+      }
+      if (r == me) {
+        ch.my_t0 = t0;
+        ch.my_n = n;
+      }
+    }
+    if (!any) continue;
+    w->chunks.push_back(ch);
+    cco.push_back(table);
+  }
+  for (int q = 0; q < 2; q++) {
+    if (!w->ev_stage_ready[q]) BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_stage_ready[q], hipEventDisableTiming));
+    if (!w->ev_stage_free[q]) BA_HIP_CHECK(hipEventCreateWithFlags(&w->ev_stage_free[q], hipEventDisableTiming));
+  }
+  return upload_chunk_tables(w, cco, col_chunk, sparse);
+}
+
 static int build_chunks(ba_problem *p, LMWorkFull *w) {
+  {
+    const char *e = getenv("BA_ASSEMBLY");  // reduce: every chunk onto ONE owner (round 3's form); default: reduce-scatter
+    if (!(e && e[0] == 'r' && e[1] == 'e' && e[2] == 'd' && e[3] == 'u' && e[4] == 'c' && e[5] == 'e' && e[6] == 0)) return build_chunks_rs(p, w);
+  }
   const DenseLDL &l = w->ldl;
   const int64_t nt = l.nt;
   const int P = l.world;
@@ -388,6 +501,14 @@ static int build_chunks(ba_problem *p, LMWorkFull *w) {
     }
     flush();
   }
+  return upload_chunk_tables(w, cco, col_chunk, sparse);
+}
+
+// the keys of every chunk, its offset table on the device, the staging buffer
+static int upload_chunk_tables(LMWorkFull *w, std::vector<std::vector<int64_t>> &cco, const std::vector<int> &col_chunk, bool sparse) {
+  const DenseLDL &l = w->ldl;
+  const int64_t nt = l.nt;
+  const SchurTasks &T = w->tasks;
   // keys per chunk (a block touches tile columns 9 cb / NB and (9 cb + 8) / NB)
   const size_t nc = w->chunks.size();
   std::vector<std::vector<int>> keys(nc), skeys(nc);
@@ -560,6 +681,10 @@ void lm_free(ba_problem *p) {
     if (c.cco_alloc) (void)hipFree(c.cco_alloc);
     if (c.keys) (void)hipFree(c.keys);
     if (c.skeys) (void)hipFree(c.skeys);
+  }
+  for (int q = 0; q < 2; q++) {
+    if (w->ev_stage_ready[q]) (void)hipEventDestroy(w->ev_stage_ready[q]);
+    if (w->ev_stage_free[q]) (void)hipEventDestroy(w->ev_stage_free[q]);
   }
   if (w->stage) (void)hipFree(w->stage);
   if (w->stage32) (void)hipFree(w->stage32);
@@ -766,6 +891,13 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
   }
   // (single-rank direct path: the right-hand side buffer is cleared by this kernel instead of a memset node of its own)
   const bool rhs_here = !w->pcg && !w->ldl.own_only;
+  // recorded sequences read the damping from pinned host memory (h_lambda).  In k_schur_prep every wave would fetch that
+  // scalar over PCIe -- unnoticeable for the few thousand waves of a small problem, where the saved copy node pays, but 15 k
+  // waves on the Venice shape and 70 k on Final-13682's: there one thread copies it to device memory first
+  if (h_lambda && p->npnts > 200000) {
+    BA_CHECK(launch_publish(h_lambda, 1, const_cast<double *>(d_lambda), nullptr, 0, nullptr, nullptr, nullptr, st));
+    h_lambda = nullptr;
+  }
   BA_CHECK(launch_schur_prep(p, lambda, w->Hpp, w->gp, w->Uinv, w->u, st, h_lambda ? h_lambda : d_lambda, damp,
                              h_lambda ? const_cast<double *>(d_lambda) : nullptr, rhs_here ? w->rhs : nullptr, rhs_here ? w->npad : 0));
   if (w->pcg) {  // the reduced camera system is applied, not formed (pcg_solve); no column scaling: block Jacobi has its own
@@ -785,6 +917,45 @@ static int linear_step(ba_problem *p, LMWorkFull *w, double lambda, int normaliz
     // per-rank ownership of S: chunk by chunk -- this rank's share of the chunk's sums goes straight into its own tiles
     // when it owns the chunk, else into the staging buffer -- and every chunk is reduced onto its owner at once
     BA_CHECK(launch_schur_pre(p, &w->tasks, Jl, w->Uinv, w->Yobs, st));
+    if (w->assembly_rs) {
+      // reduce-scatter form (build_chunks_rs): every chunk is one slice of EVERY owner's columns, assembled into a staging
+      // buffer of `world` segments and reduce-scattered in place; the owner copies its segment into its tiles.  With two
+      // buffers the transfer of chunk c (transfer stream) runs beside the assembly of chunk c+1 (main stream).
+      const int bufs = w->stage_bufs, me = w->ldl.rank;
+      const int64_t buf_elems = (w->stage_tiles / bufs) * NB * NB;
+      hipStream_t ts = bufs == 2 ? w->ldl.hoist : st;
+      bool used[2] = {false, false};
+      int ci = 0;
+      for (const SchurChunk &c : w->chunks) {
+        const int b = bufs == 2 ? (ci++ & 1) : 0;
+        double *dst = w->stage + b * buf_elems;
+        if (bufs == 2 && used[b]) BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_stage_free[b], 0));  // its last transfer is through
+        BA_CHECK(launch_schur_chunk(p, &w->tasks, &c, Jl, w->Yobs, w->Hcc, lam_diag, dst, w->n, p->rank == 0 ? w->npad : w->n, st,
+                                    d_lambda, damp));
+        const int64_t seg_elems = c.seg * NB * NB, my_elems = c.my_n * NB * NB;
+        float *d32 = reduce32 ? w->stage32 + b * buf_elems : nullptr;
+        if (reduce32) BA_CHECK(launch_convert(dst, d32, c.ntiles * NB * NB, st));
+        if (bufs == 2) {
+          BA_HIP_CHECK(hipEventRecord(w->ev_stage_ready[b], st));
+          BA_HIP_CHECK(hipStreamWaitEvent(ts, w->ev_stage_ready[b], 0));
+        }
+        BA_CHECK(comm_reduce_scatter(p, reduce32 ? (void *)d32 : (void *)dst, seg_elems, reduce32, ts));
+        if (my_elems > 0) {
+          if (reduce32)
+            BA_HIP_CHECK(hipMemcpyAsync(w->ldl32.S + c.my_t0 * NB * NB, d32 + (int64_t)me * seg_elems, (size_t)my_elems * sizeof(float),
+                                        hipMemcpyDeviceToDevice, ts));
+          else
+            BA_HIP_CHECK(hipMemcpyAsync(w->ldl.S + c.my_t0 * NB * NB, dst + (int64_t)me * seg_elems, (size_t)my_elems * sizeof(double),
+                                        hipMemcpyDeviceToDevice, ts));
+        }
+        if (bufs == 2) {
+          BA_HIP_CHECK(hipEventRecord(w->ev_stage_free[b], ts));
+          used[b] = true;
+        }
+      }
+      for (int b = 0; b < 2; b++)
+        if (used[b]) BA_HIP_CHECK(hipStreamWaitEvent(st, w->ev_stage_free[b], 0));
+    } else
     for (const SchurChunk &c : w->chunks) {
       const bool mine = c.owner == w->ldl.rank;
       double *dest = mine ? w->ldl.S + c.t0 * NB * NB : w->stage;
@@ -1168,6 +1339,10 @@ static inline TS mul(TS a, TS b) { return both32(a, b) ? f32((float)a.v * (float
 static inline TS div(TS a, TS b) { return both32(a, b) ? f32((float)a.v / (float)b.v) : f64(a.v / b.v); }
 static inline TS max(TS a, TS b) { return TS{a.v > b.v ? a.v : b.v, both32(a, b) ? 32 : 64}; }
 static inline TS sqrt(TS a) { return a.w == 32 ? f32(std::sqrt((float)a.v)) : f64(std::sqrt(a.v)); }
+// x^n with a variable Int n (lm.jl:308,331).  The reference ran on Julia 1.3 / 1.4 (.travis.yml:6-9), whose
+// ^(x::Float64, y::Integer) and ^(x::Float32, y::Integer) are llvm.pow of the exponent CONVERTED to the base's type
+// (base/math.jl there; power_by_squaring is the generic fallback for other number types and only became the float path in
+// Julia 1.8's pow_body): pow() / powf() of the rounded exponent is that operation.
 static inline TS powi(TS a, int n) { return a.w == 32 ? f32(std::pow((float)a.v, (float)n)) : f64(std::pow(a.v, (double)n)); }
 }  // namespace ts
 

@@ -31,8 +31,9 @@ struct SchurTasks {
 // one chunk of tile columns of the reduced camera matrix in a distributed run with per-rank ownership of S: the columns
 // [owner's local tile range t0 .. t0 + ntiles), the keys whose 9 x 9 blocks touch them, its offset table (negative: not here)
 struct SchurChunk {
-  int owner = 0;
+  int owner = 0;           // -1: a reduce-scatter chunk -- one segment per owner, `seg` tiles each, laid out by rank
   int64_t t0 = 0, ntiles = 0;
+  int64_t seg = 0, my_t0 = 0, my_n = 0;  // reduce-scatter chunk: tiles per segment; where this rank's segment goes in its own S
   int64_t *cco = nullptr;  // device, nt entries (cco_alloc + 1: tix reads the table's head one entry before)
   int64_t *cco_alloc = nullptr;
   int *keys = nullptr, *skeys = nullptr;  // device: key ids / indices into the split-key list

@@ -105,8 +105,10 @@ class CameraBlockReducer:
             # (include/ba_hip.h).  `stream` is the transfer stream of the distributed factorisation's look-ahead as often as
             # the handle's main stream; both are non-blocking, a null-stream copy has no ordering against either.
             try:
-                esize, view = {_lib.COMM_BCAST_BYTES: (1, np.uint8), _lib.COMM_REDUCE_F32: (4, np.float32)}.get(op, (8, np.float64))
-                nbytes = esize * count
+                esize, view = {_lib.COMM_BCAST_BYTES: (1, np.uint8), _lib.COMM_REDUCE_F32: (4, np.float32),
+                               _lib.COMM_REDUCE_SCATTER_F32: (4, np.float32)}.get(op, (8, np.float64))
+                scatter = op in (_lib.COMM_REDUCE_SCATTER_F64, _lib.COMM_REDUCE_SCATTER_F32)
+                nbytes = esize * count * (self.world if scatter else 1)
                 host = np.empty(nbytes, dtype=np.uint8)
                 st = C.c_void_p(stream)
                 sends = not (op == _lib.COMM_BCAST_BYTES and self.rank != root)  # a broadcast's receivers have nothing to read
@@ -124,6 +126,13 @@ class CameraBlockReducer:
                     dist.broadcast(t, src=src(root), group=group)
                     if self.rank == root:
                         return 0
+                elif scatter:
+                    # gloo has no reduce-scatter: the whole buffer is summed and this rank's segment goes back (a test
+                    # transport: the bytes on the wire are not what RCCL's reduce-scatter moves)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    seg = esize * count
+                    _lib.check(L.ba_memcpy_h2d_on(h, st, C.c_void_p(d_buf + self.rank * seg), _lib.ptr(host[self.rank * seg:(self.rank + 1) * seg]), seg))
+                    return 0
                 else:
                     return 2
                 _lib.check(L.ba_memcpy_h2d_on(h, st, C.c_void_p(d_buf), _lib.ptr(host), nbytes))
@@ -134,12 +143,20 @@ class CameraBlockReducer:
                 return 1
 
         self._cb = _lib.COMM_CB(_hook)  # keep alive as long as the handle may call it
+        nlp._comm_hook_owner = self    # ... i.e. as long as the model lives, whether or not the caller keeps this object
         _lib.check(L.ba_lm_set_comm_hook(nlp.handle, self.rank, self.world, self._cb, None))
 
     def _stats(self):
         calls, nbytes = C.c_int64(0), C.c_int64(0)
         self._lib.check(self._lib.lib().ba_comm_stats(self.nlp.handle, C.byref(calls), C.byref(nbytes)))
         return calls.value, nbytes.value
+
+    def stats_by_op(self):
+        """{operation: (calls, bytes handed to the transport by this rank)} since the communicator was attached"""
+        calls = (C.c_int64 * self._lib.COMM_OPS)()
+        nbytes = (C.c_int64 * self._lib.COMM_OPS)()
+        self._lib.check(self._lib.lib().ba_comm_stats_ops(self.nlp.handle, calls, nbytes))
+        return {self._lib.COMM_OP_NAMES[q]: (int(calls[q]), int(nbytes[q])) for q in range(self._lib.COMM_OPS) if calls[q]}
 
     @property
     def calls(self):

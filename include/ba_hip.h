@@ -189,13 +189,18 @@ int ba_lm_solve(ba_problem *p, const ba_lm_opts *opts, double *x_inout, ba_lm_st
  *   ba_lm_set_comm_hook : the host carries the data.  op: BA_COMM_ALLREDUCE_F64 (count doubles, sum, in place),
  *                         BA_COMM_REDUCE_F64 / BA_COMM_REDUCE_F32 (count doubles / floats, the sum lands on `root` only,
  *                         in place; the Float32 form carries the reduced camera matrix of facto_type = Float32 runs),
- *                         BA_COMM_BCAST_BYTES (count bytes from `root`).  d_buf is a device pointer; the operation must
+ *                         BA_COMM_BCAST_BYTES (count bytes from `root`), BA_COMM_REDUCE_SCATTER_F64 / _F32 (see the enum).
+ *                         d_buf is a device pointer; the operation must
  *                         be ordered after prior work on `stream` and complete (or stream-ordered ON `stream`) on return:
  *                         `stream` is not always the handle's main stream (the distributed factorisation hands its
  *                         panels over on a second, transfer stream while the trailing update runs on the main one), and
  *                         both are hipStreamNonBlocking -- a host-staged hook copies with ba_memcpy_d2h_on /
  *                         ba_memcpy_h2d_on(p, stream, ...), never on the null stream. */
-enum { BA_COMM_ALLREDUCE_F64 = 0, BA_COMM_REDUCE_F64 = 1, BA_COMM_BCAST_BYTES = 2, BA_COMM_REDUCE_F32 = 3 };
+enum { BA_COMM_ALLREDUCE_F64 = 0, BA_COMM_REDUCE_F64 = 1, BA_COMM_BCAST_BYTES = 2, BA_COMM_REDUCE_F32 = 3,
+       /* d_buf holds `world` segments of `count` doubles / floats; on return segment `rank` (at d_buf + rank * count)
+        * holds the sum of that segment over the ranks, the other segments are unspecified; `root` is unused.  What the
+        * assembly of the reduced camera matrix uses: every link of every GPU carries 1 / world of a chunk */
+       BA_COMM_REDUCE_SCATTER_F64 = 4, BA_COMM_REDUCE_SCATTER_F32 = 5, BA_COMM_OPS = 6 };
 #define BA_COMM_ID_BYTES 128
 typedef int (*ba_comm_fn)(void *ctx, int op, void *d_buf, int64_t count, int root, void *stream);
 int ba_comm_get_unique_id(void *id_out /* BA_COMM_ID_BYTES */);
@@ -208,6 +213,9 @@ int ba_lm_set_comm_hook(ba_problem *p, int rank, int world, ba_comm_fn fn, void 
 int ba_dist_layout(int64_t nt, int world, int64_t *col_off, int64_t *own_range);
 /* number of transport calls / bytes handed to the transport since the communicator was attached */
 int ba_comm_stats(ba_problem *p, int64_t *calls, int64_t *bytes);
+/* the same per operation kind: calls[BA_COMM_OPS], bytes[BA_COMM_OPS], indexed by the BA_COMM_* codes (bytes: what one rank
+ * hands to the transport) */
+int ba_comm_stats_ops(ba_problem *p, int64_t *calls, int64_t *bytes);
 
 /* ---- single linear step, exposed for parity tests and profiling ------------------------------------
  * From (x, lambda): delta (nvar) solving (J'J + lambda I) delta = -J' r, and pred2 = 1/2 |J delta + r|^2

@@ -41,7 +41,7 @@ def main():
     warr = ba.synthetic.as_arrays(wide)
     wl, winfo = ba.parallel.shard_problem(warr, rank, world)
     wn = ba.BALNLPModel(arrays=wl, device=0)
-    ba.parallel.CameraBlockReducer(wn)
+    wred = ba.parallel.CameraBlockReducer(wn)  # noqa: F841 (the model keeps it alive too)
     dw, halfw, _ = ba.lm_step(wn, wl[3], 10.0)
     dw = ba.parallel.gather_solution(dw, winfo, wide["ncams"])
     # facto = :PCG on the shards: the product S v is all-reduced once per CG iteration, everything else is replicated

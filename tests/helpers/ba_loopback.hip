@@ -120,20 +120,23 @@ extern "C" void *ba_loopback_rank(void *h, int rank) {
 
 extern "C" long ba_loopback_ops(void *h) { return h ? static_cast<Loop *>(h)->ops : -1; }
 
-// the hook (ba_comm_fn).  op codes of include/ba_hip.h: 0 all-reduce f64, 1 reduce f64 onto root, 2 broadcast bytes, 3 reduce f32
+// the hook (ba_comm_fn).  op codes of include/ba_hip.h: 0 all-reduce f64, 1 reduce f64 onto root, 2 broadcast bytes, 3 reduce f32,
+// 4 / 5 reduce-scatter f64 / f32 (in place: segment `rank` of the buffer receives the sum)
 extern "C" int ba_loopback_hook(void *ctx, int op, void *d_buf, int64_t count, int root, void *stream) {
   RankCtx *c = static_cast<RankCtx *>(ctx);
   Loop *L = c->L;
   const int me = c->rank, W = L->world;
   hipStream_t st = (hipStream_t)stream;
-  const size_t bytes = (size_t)count * (op == 2 ? 1 : (op == 3 ? 4 : 8));
-  if (op < 0 || op > 3 || bytes > L->cap) {
+  const bool rs = op == 4 || op == 5;  // reduce-scatter: `world` segments of `count` elements, segment `me` receives the sum
+  const size_t esize = op == 2 ? 1 : ((op == 3 || op == 5) ? 4 : 8);
+  const size_t bytes = (size_t)count * esize * (rs ? (size_t)W : 1);
+  if (op < 0 || op > 5 || bytes > L->cap) {
     fprintf(stderr, "[loopback] op %d with %zu bytes: unsupported or beyond the staging buffers (%zu)\n", op, bytes, L->cap);
     return 2;
   }
   const bool bcast = op == 2, allred = op == 0;
   const bool sends = !bcast || me == root;
-  const bool receives = allred || (bcast ? me != root : me == root);
+  const bool receives = allred || rs || (bcast ? me != root : me == root);
   // the previous operation's consumers are through with the staging buffers (their events were recorded before that
   // operation's second rendezvous, i.e. before any rank got here)
   for (int r = 0; r < W; r++) LB_CHECK(hipStreamWaitEvent(st, L->ev_out[r], 0));
@@ -147,14 +150,15 @@ extern "C" int ba_loopback_hook(void *ctx, int op, void *d_buf, int64_t count, i
     } else {
       for (int r = 0; r < W; r++) LB_CHECK(hipStreamWaitEvent(st, L->ev_in[r], 0));
       Ptrs src;
-      for (int r = 0; r < MAXW; r++) src.p[r] = r < W ? L->stage[r] : nullptr;
+      const size_t seg = rs ? (size_t)me * (size_t)count * esize : 0;  // reduce-scatter: this rank's segment of every buffer
+      for (int r = 0; r < MAXW; r++) src.p[r] = r < W ? (const char *)L->stage[r] + seg : nullptr;
       const int64_t n = count;
       int64_t nb = (n + 255) / 256;
       if (nb > 4096) nb = 4096;
-      if (op == 3)
-        hipLaunchKernelGGL(k_rank_order_sum<float>, dim3((unsigned)nb), dim3(256), 0, st, (float *)d_buf, src, W, n);
+      if (esize == 4)
+        hipLaunchKernelGGL(k_rank_order_sum<float>, dim3((unsigned)nb), dim3(256), 0, st, (float *)((char *)d_buf + seg), src, W, n);
       else
-        hipLaunchKernelGGL(k_rank_order_sum<double>, dim3((unsigned)nb), dim3(256), 0, st, (double *)d_buf, src, W, n);
+        hipLaunchKernelGGL(k_rank_order_sum<double>, dim3((unsigned)nb), dim3(256), 0, st, (double *)((char *)d_buf + seg), src, W, n);
       LB_CHECK(hipGetLastError());
     }
   }

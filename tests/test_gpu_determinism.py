@@ -396,6 +396,61 @@ def test_loopback_block_sparse_on_several_ranks(ba, loopback, world, irregular):
         os.environ.pop("BA_CAM_ORDER", None)
 
 
+@pytest.mark.parametrize("world,ncams,npnts,nobs", [(2, 200, 1500, 9000), (3, 640, 5000, 36000)])
+def test_loopback_reduce_scatter_assembly_equals_reduce_onto_owner(ba, loopback, world, ncams, npnts, nobs):
+    """The chunked assembly of the reduced camera matrix in its reduce-scatter form (default: a chunk = one slice of every
+    owner's tile columns, one in-place reduce-scatter, two staging buffers so that a chunk travels on the transfer stream
+    while the next is assembled) against round 3's form (BA_ASSEMBLY=reduce: a chunk = a range of ONE owner's columns,
+    reduced onto it).  The loopback transport sums in rank order in both, so the steps must be the SAME BITS (Float64 and
+    Float32 factorisation); the per-operation counters show one reduce-scatter per chunk and no reduce; a rank's staging
+    stays within half its share of S (small problems: one buffer) and the second run of the same handles gives the same bits."""
+    prob = ba.synthetic.make_problem(ncams, npnts, nobs, seed=11)
+    ref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob))
+    d_ref, _, _ = ba.lm_step(ref, prob["x0"], 10.0)
+    ref.close()
+    out = {}
+    for form in ("reduce-scatter", "reduce"):
+        if form == "reduce":
+            os.environ["BA_ASSEMBLY"] = "reduce"
+        try:
+            R = _Ranks(ba, loopback, prob, world, stage_mb=512)
+            try:
+                d, cams, _ = R.step(10.0)
+                d2, cams2, _ = R.step(10.0)
+                d32, cams32, _ = R.step(10.0, facto_type=np.float32)
+                e = rel_err(d, d_ref)
+                assert e <= 1e-9, f"{form}: relative difference to the one-rank step {e:.3e}"
+                rep = bits_report(cams[0], cams2[0], f"{form}: first vs second step on the same handles")
+                assert not rep, rep
+                for r in range(1, world):
+                    rep = bits_report(cams[0], cams[r], f"{form}: camera step of rank 0 vs rank {r}")
+                    assert not rep, rep
+                calls = (C.c_int64 * ba._lib.COMM_OPS)()
+                nbytes = (C.c_int64 * ba._lib.COMM_OPS)()
+                ba._lib.check(ba._lib.lib().ba_comm_stats_ops(R.models[0].handle, calls, nbytes))
+                ops = {ba._lib.COMM_OP_NAMES[q]: (int(calls[q]), int(nbytes[q])) for q in range(ba._lib.COMM_OPS)}
+                mem = [ba.schur_memory(m) for m in R.models]
+                out[form] = (cams[0], cams32[0], ops, mem)
+            finally:
+                R.close()
+        finally:
+            os.environ.pop("BA_ASSEMBLY", None)
+    for tag, idx in (("Float64", 0), ("Float32 factorisation", 1)):
+        rep = bits_report(out["reduce-scatter"][idx], out["reduce"][idx], f"{tag} camera step, reduce-scatter vs reduce-onto-owner assembly")
+        assert not rep, rep
+    ops_rs, ops_red = out["reduce-scatter"][2], out["reduce"][2]
+    print("reduce-scatter form:", {k: v for k, v in ops_rs.items() if v[0]}, "memory", out["reduce-scatter"][3])
+    print("reduce form:        ", {k: v for k, v in ops_red.items() if v[0]}, "memory", out["reduce"][3])
+    assert ops_rs["reduce_scatter_f64"][0] > 0 and ops_rs["reduce_scatter_f32"][0] > 0 and ops_rs["reduce_f64"][0] == 0 and ops_rs["reduce_f32"][0] == 0
+    assert ops_red["reduce_scatter_f64"][0] == 0 and ops_red["reduce_f64"][0] > 0
+    # all staging within half the largest share plus two tile columns (slices are whole tile columns: on a matrix this small a
+    # column is a quarter of a share)
+    nt = int(np.sqrt(2 * out["reduce-scatter"][3][0][0]))
+    biggest = max(h for _, h, _ in out["reduce-scatter"][3])
+    for (full, held, staging) in out["reduce-scatter"][3]:
+        assert staging <= 0.5 * biggest + 2 * nt + 2, f"staging {staging} tiles, largest share {biggest}, {nt} tile rows"
+
+
 def test_loopback_camera_ordering_on_several_ranks(ba, loopback):
     """A randomly numbered block-banded problem on 3 ranks: every rank sees only the camera pairs ITS points connect; the
     camera graph is summed over the ranks before it is ordered, so every handle arrives at the sequence (and the pattern)
