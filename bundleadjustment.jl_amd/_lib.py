@@ -55,7 +55,7 @@ SYMBOLS = [
     "ba_problem_create", "ba_problem_destroy", "ba_problem_dims", "ba_residual", "ba_residual_f32",
     "ba_jac_structure", "ba_jac_coord", "ba_jac_coord_f32", "ba_jtr", "ba_residual_dev", "ba_residual_f32_dev",
     "ba_jac_structure_dev", "ba_jac_coord_dev", "ba_jac_coord_f32_dev", "ba_jtr_dev", "ba_dev_malloc", "ba_dev_free",
-    "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_memcpy_h2d_on", "ba_memcpy_d2h_on", "ba_synchronize", "ba_lm_solve", "ba_comm_get_unique_id", "ba_lm_set_comm_rccl",
+    "ba_memcpy_h2d", "ba_memcpy_d2h", "ba_memcpy_h2d_on", "ba_memcpy_d2h_on", "ba_synchronize", "ba_lm_solve", "ba_lm_solve_dev", "ba_comm_get_unique_id", "ba_lm_set_comm_rccl",
     "ba_lm_set_comm_hook", "ba_comm_stats", "ba_comm_stats_ops", "ba_dist_layout",
     "ba_lm_step", "ba_lm_step_f32", "ba_lm_step_pcg", "ba_lm_schur_pattern", "ba_lm_schur_memory", "ba_schur_ordering", "ba_lm_set_ordering", "ba_lm_schur_ordering", "ba_profile_enable", "ba_profile_reset", "ba_profile_get", "ba_dense_ldl_solve", "ba_dense_ldl_solve_f32",
 ]
@@ -97,6 +97,7 @@ def lib():
     L.ba_memcpy_d2h_on.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.ba_synchronize.argtypes = [vp]
     L.ba_lm_solve.argtypes = [vp, C.POINTER(LMOpts), vp, C.POINTER(LMStats), LOG_CB, vp]
+    L.ba_lm_solve_dev.argtypes = [vp, C.POINTER(LMOpts), vp, C.POINTER(LMStats), LOG_CB, vp]
     L.ba_comm_get_unique_id.argtypes = [vp]
     L.ba_lm_set_comm_rccl.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ba_lm_set_comm_hook.argtypes = [vp, C.c_int, C.c_int, COMM_CB, vp]

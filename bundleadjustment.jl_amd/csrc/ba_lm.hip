@@ -1346,8 +1346,21 @@ static inline TS sqrt(TS a) { return a.w == 32 ? f32(std::sqrt((float)a.v)) : f6
 static inline TS powi(TS a, int n) { return a.w == 32 ? f32(std::pow((float)a.v, (float)n)) : f64(std::pow(a.v, (double)n)); }
 }  // namespace ts
 
+static int lm_solve_impl(ba_problem *p, const ba_lm_opts *o, double *x_inout, bool x_on_device, ba_lm_stats *stats, ba_log_cb cb,
+                         void *cb_ctx);
+
 extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, ba_lm_stats *stats, ba_log_cb cb,
                            void *cb_ctx) {
+  return lm_solve_impl(p, o, x_inout, false, stats, cb, cb_ctx);
+}
+
+extern "C" int ba_lm_solve_dev(ba_problem *p, const ba_lm_opts *o, double *d_x_inout, ba_lm_stats *stats, ba_log_cb cb,
+                               void *cb_ctx) {
+  return lm_solve_impl(p, o, d_x_inout, true, stats, cb, cb_ctx);
+}
+
+static int lm_solve_impl(ba_problem *p, const ba_lm_opts *o, double *x_inout, bool x_on_device, ba_lm_stats *stats, ba_log_cb cb,
+                         void *cb_ctx) {
   if (!p || !o || !x_inout || !stats) {
     ba_set_error("ba_lm_solve: null argument");
     return BA_ERR_ARG;
@@ -1443,7 +1456,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   stats->status = BA_ST_UNKNOWN;
   double *h_sh = w->s.h_sh, *h_rp = w->s.h_rp;
 
-  BA_HIP_CHECK(hipMemcpyAsync(w->x, x_inout, (size_t)w->nvar * sizeof(double), hipMemcpyHostToDevice, st));
+  BA_HIP_CHECK(hipMemcpyAsync(w->x, x_inout, (size_t)w->nvar * sizeof(double), x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   if (xf32) {  // x0 is a Float32 vector at the reference's boundary; make sure of it
     BA_CHECK(launch_convert(w->x, w->xf, w->nvar, st));
     BA_CHECK(launch_convert(w->xf, w->x, w->nvar, st));
@@ -1604,7 +1617,7 @@ extern "C" int ba_lm_solve(ba_problem *p, const ba_lm_opts *o, double *x_inout, 
   stats->n_cg = (int)w->n_cg;
   w->pcg = false;
   {
-    hipError_t e = hipMemcpyAsync(x_inout, w->x, (size_t)w->nvar * sizeof(double), hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(x_inout, w->x, (size_t)w->nvar * sizeof(double), x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess && rc == BA_OK) {
       ba_set_error("solution copy: %s", hipGetErrorString(e));

@@ -55,7 +55,10 @@ def _sym(s):
 def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=None, facto_type=None,
                         restol=None, satol=None, srtol=None, oatol=None, ortol=None, atol=None, rtol=None,
                         nu_d=None, nu_m=None, lam=None, delta_d=None, ite_max=None, max_time=None, verbose=False,
-                        log=True, pcg_tol=None, pcg_max_iter=None):
+                        log=True, pcg_tol=None, pcg_max_iter=None, x_device_ptr=None):
+    """x_device_ptr (an extension for device-resident callers, e.g. bench.py): the address of nvar doubles of DEVICE memory
+    holding x0; the loop then runs through ba_lm_solve_dev -- no host copy of the iterate on either side -- the solution
+    stays there and `solution` of the result is None."""
     facto, perm, normalize = _sym(facto), _sym(perm), _sym(normalize)
     if facto not in _FACTO:
         raise ValueError(f"facto must be :QR, :LDL or :PCG (extension: matrix-free CG on the reduced camera system), got {facto!r}")
@@ -70,8 +73,10 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
     variant = 0 if linesearch is None else 1
     if variant == 0 and (facto_type is not None or max_time is not None):
         raise TypeError("LevenbergMarquardt.jl's Levenberg_Marquardt has no facto_type / max_time keyword")
-    x0 = np.array(nlp.meta.x0 if x is None else x, dtype=np.float64, copy=True)
-    if x0.shape != (nlp.meta.nvar,):
+    if x_device_ptr is not None and x is not None:
+        raise TypeError("x and x_device_ptr are exclusive")
+    x0 = None if x_device_ptr is not None else np.array(nlp.meta.x0 if x is None else x, dtype=np.float64, copy=True)
+    if x0 is not None and x0.shape != (nlp.meta.nvar,):
         raise ValueError("x has the wrong length")
     if facto_type is not None and np.dtype(facto_type) not in (np.dtype(np.float64), np.dtype(np.float32), np.dtype(np.float16)):
         raise TypeError("facto_type must be Float64, Float32 or Float16")
@@ -103,12 +108,15 @@ def Levenberg_Marquardt(model, facto, perm, normalize, linesearch=None, *, x=Non
         rows.append((it, f, df, njtr, lmb, nd, rho, bool(acc)))
 
     cb = _lib.LOG_CB(_cb) if log else C.cast(None, _lib.LOG_CB)
-    _lib.check(_lib.lib().ba_lm_solve(nlp.handle, C.byref(o), _lib.ptr(x0), C.byref(st), cb, None))
+    if x_device_ptr is not None:
+        _lib.check(_lib.lib().ba_lm_solve_dev(nlp.handle, C.byref(o), C.c_void_p(int(x_device_ptr)), C.byref(st), cb, None))
+    else:
+        _lib.check(_lib.lib().ba_lm_solve(nlp.handle, C.byref(o), _lib.ptr(x0), C.byref(st), cb, None))
     nlp.counters.neval_cons += st.n_residual
     nlp.counters.neval_residual += st.n_residual
     nlp.counters.neval_jac += st.n_jacobian + 1  # + jac_structure! (src/BALNLPModels.jl:126)
     nlp.counters.neval_jac_residual += st.n_jacobian
-    out = GenericExecutionStats(status=_lib.STATUS[st.status], solution=x0.astype(nlp.T) if xf32 else x0, objective=st.objective, iter=st.iter,
+    out = GenericExecutionStats(status=_lib.STATUS[st.status], solution=None if x0 is None else (x0.astype(nlp.T) if xf32 else x0), objective=st.objective, iter=st.iter,
                                 elapsed_time=st.elapsed_s, loop_time=st.loop_s, n_accepted=st.n_accepted,
                                 n_rejected=st.n_rejected, n_residual=st.n_residual, n_jacobian=st.n_jacobian,
                                 n_factor=st.n_factor, lambda_final=st.lambda_final, log=rows, n_cg=st.n_cg)

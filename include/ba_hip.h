@@ -175,6 +175,11 @@ typedef void (*ba_log_cb)(void *ctx, int iter, double f, double df, double norm_
 /* x_inout: nvar doubles, x0 in, solution out (the `x=` keyword of src/lm.jl:20). */
 int ba_lm_solve(ba_problem *p, const ba_lm_opts *opts, double *x_inout, ba_lm_stats *stats, ba_log_cb cb,
                 void *cb_ctx);
+/* the same with the iterate resident on the device (d_x_inout: nvar doubles of device memory, e.g. from ba_dev_malloc): no
+ * host <-> device copy of x on either side of the loop.  What bench.py times (inputs resident in HBM when the timed region
+ * starts); a host that keeps x in its own memory, as the reference does, calls ba_lm_solve. */
+int ba_lm_solve_dev(ba_problem *p, const ba_lm_opts *opts, double *d_x_inout, ba_lm_stats *stats, ba_log_cb cb,
+                    void *cb_ctx);
 
 /* ---- multi-GPU: observations sharded by point, cameras replicated --------------------------------
  * One process per GPU.  Every rank creates its own shard (ba_problem_create: local observations and points, ALL

@@ -69,6 +69,32 @@ def test_lm_step_twice_same_bits_venice_scaled(ba, gpu_ok):
 
 
 
+def test_lm_solve_with_the_iterate_on_the_device_same_bits(ba, gpu_ok):
+    """ba_lm_solve_dev (the iterate resident in device memory: what bench.py times) against ba_lm_solve (host vectors, the
+    reference's boundary): same iterations, status, log rows and the same bits in the solution."""
+    import ctypes
+    p = ba.synthetic.make_problem(40, 900, 4200, seed=17)
+    m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+    fr = ba.FeasibilityResidual(m)
+    a = ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False)
+    L = ba._lib.lib()
+    nbytes = 8 * m.meta.nvar
+    d_x = ctypes.c_void_p()
+    ba._lib.check(L.ba_dev_malloc(m.handle, nbytes, ctypes.byref(d_x)))
+    try:
+        x0 = np.ascontiguousarray(p["x0"], dtype=np.float64)
+        ba._lib.check(L.ba_memcpy_h2d(m.handle, d_x, ba._lib.ptr(x0), nbytes))
+        b = ba.Levenberg_Marquardt(fr, "LDL", "AMD", "None", False, x_device_ptr=d_x.value)
+        out = np.empty(m.meta.nvar)
+        ba._lib.check(L.ba_memcpy_d2h(m.handle, ba._lib.ptr(out), d_x, nbytes))
+    finally:
+        ba._lib.check(L.ba_dev_free(m.handle, d_x))
+        m.close()
+    assert b.solution is None and a.iter == b.iter and a.status == b.status and a.log == b.log and a.objective == b.objective
+    rep = bits_report(a.solution, out, "solution: ba_lm_solve vs ba_lm_solve_dev")
+    assert not rep, rep
+
+
 def _env(key, value, fn):
     old = os.environ.get(key)
     if value is None:
