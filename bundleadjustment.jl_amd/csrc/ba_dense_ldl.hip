@@ -553,6 +553,17 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(T *__restrict__ Skk, 
   diag_tile<T, DIAG_THREADS / 64>(Skk, Linv_k, D_k, flag, stamps, reinterpret_cast<T *>(smraw));
 }
 
+// two diagonal tiles per launch (two independent runs of the block-sparse schedule: see "two runs per launch" below)
+template <typename T>
+__global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag2(T *__restrict__ SkkA, T *__restrict__ LinvA, T *__restrict__ DA,
+                                                    T *__restrict__ SkkB, T *__restrict__ LinvB, T *__restrict__ DB,
+                                                    int *__restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  const bool second = blockIdx.x == 1;
+  diag_tile<T, DIAG_THREADS / 64>(second ? SkkB : SkkA, second ? LinvB : LinvA, second ? DB : DA, flag, (unsigned long long *)nullptr,
+                                  reinterpret_cast<T *>(smraw));
+}
+
 // ---- 128 x 128 x (128 NP) tile product C = sum_p A_p * B_p' on the matrix cores ------------------------------------
 // A_p, B_p: contiguous row-major 128x128 tiles in global memory.  256 threads = 4 waves, wave w owns the 64x64
 // quadrant (w >> 1, w & 1) as 4x4 MFMA blocks (128 accumulator VGPRs).  K is consumed in chunks of KC = 16 staged
@@ -785,16 +796,15 @@ __device__ inline void tile_gemm_rows(const T *__restrict__ A, const T *__restri
 // rows [32 rq, 32 rq + 32) of X_i = S_ik Linv_k' -> V_i, S_ik = X_i D_k^-1; FWD: y_k and b_i -= L_ik y_k ride along.
 // grid = 4 (nt-k-1): i = k + 1 + blockIdx.x / 4, rq = blockIdx.x % 4
 template <typename T, bool FWD>
-__global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv_k,
-                                                      const T *__restrict__ D_k, T *__restrict__ V, int k,
-                                                      T *__restrict__ b, T *__restrict__ y,
-                                                      const int *__restrict__ rows = nullptr) {
+__device__ inline void ldl_trsm_rs_body(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv_k,
+                                        const T *__restrict__ D_k, T *__restrict__ V, int k, T *__restrict__ b, T *__restrict__ y,
+                                        const int *__restrict__ rows, const int bid) {
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
   T *sA = lds, *sB = lds + 2 * RS * LDK, *ysh = lds + 2 * (RS + NB) * LDK, *red = ysh + NB;  // red: 4 x 32
   // rows (block-sparse S): the tile rows of this panel's pattern, ascending; null: every tile row below the diagonal tile
-  const int i = rows ? rows[blockIdx.x >> 2] : k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
+  const int i = rows ? rows[bid >> 2] : k + 1 + (bid >> 2), r0 = (bid & 3) * RS;
   T *Sik = S + tix(co, i, k) * NB * NB + r0 * NB;
   T *Vi = V + (int64_t)i * NB * NB + r0 * NB;
   typename RT<T>::v4 acc[2][2];
@@ -808,7 +818,7 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const in
   if (FWD) {
     if (tid < NB) {
       ysh[tid] = yacc;
-      if (blockIdx.x == 0) y[(int64_t)k * NB + tid] = yacc;
+      if (bid == 0) y[(int64_t)k * NB + tid] = yacc;
     }
     __syncthreads();
   }
@@ -850,15 +860,45 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const in
   }
 }
 
+template <typename T, bool FWD>
+__global__ __launch_bounds__(256) void k_ldl_trsm_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv_k,
+                                                      const T *__restrict__ D_k, T *__restrict__ V, int k,
+                                                      T *__restrict__ b, T *__restrict__ y,
+                                                      const int *__restrict__ rows = nullptr) {
+  ldl_trsm_rs_body<T, FWD>(S, co, Linv_k, D_k, V, k, b, y, rows, (int)blockIdx.x);
+}
+
+// ---- two runs per launch -------------------------------------------------------------------------------------------------
+// Two independent runs of tile column pairs (TilePattern::a_clean / b_clean: a profile eliminated from both ends) advance
+// TOGETHER: every kernel of the panel chain is launched once for both runs -- the first n0 workgroups work on run A's panel,
+// the others on run B's -- so a step of two pairs costs the launches (and the latency: these kernels leave the chip almost
+// empty) of one.  What a run needs per panel: its tile column k, the inverted diagonal tile and pivots of that column, its
+// panel buffer, its row list.  (Two streams, one per run, were tried first: the replayed graph ran the two branches one after
+// the other, kernel trace profiles/r04_d_trace_final_two_streams_timeline.txt.)
+template <typename T>
+struct RunPanel {
+  const T *Linv_k, *D_k;
+  T *V;
+  int k;
+  const int *rows;
+};
+template <typename T, bool FWD>
+__global__ __launch_bounds__(256) void k_ldl_trsm_rs2(T *__restrict__ S, const int64_t *__restrict__ co, RunPanel<T> a, RunPanel<T> c, int n0,
+                                                       T *__restrict__ b, T *__restrict__ y) {
+  const bool second = (int)blockIdx.x >= n0;
+  ldl_trsm_rs_body<T, FWD>(S, co, second ? c.Linv_k : a.Linv_k, second ? c.D_k : a.D_k, second ? c.V : a.V, second ? c.k : a.k, b, y,
+                           second ? c.rows : a.rows, (int)blockIdx.x - (second ? n0 : 0));
+}
+
 // rows [32 rq, 32 rq + 32) of S_{i,k+1} -= V0_i L_{k+1,k}'   (grid = 4 (nt-k-1))
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, int k,
-                                                     const int *__restrict__ rows = nullptr) {
+__device__ inline void ldl_col_rs_body(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, int k,
+                                       const int *__restrict__ rows, const int bid) {
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
   T *sA = lds, *sB = lds + 2 * RS * LDK;
-  const int i = rows ? rows[blockIdx.x >> 2] : k + 1 + (blockIdx.x >> 2), r0 = (blockIdx.x & 3) * RS;
+  const int i = rows ? rows[bid >> 2] : k + 1 + (bid >> 2), r0 = (bid & 3) * RS;
   typename RT<T>::v4 acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; m++)
@@ -880,6 +920,17 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, int k,
+                                                     const int *__restrict__ rows = nullptr) {
+  ldl_col_rs_body<T>(S, co, V0, k, rows, (int)blockIdx.x);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_col_rs2(T *__restrict__ S, const int64_t *__restrict__ co, RunPanel<T> a, RunPanel<T> c, int n0) {
+  const bool second = (int)blockIdx.x >= n0;
+  ldl_col_rs_body<T>(S, co, second ? c.V : a.V, second ? c.k : a.k, second ? c.rows : a.rows, (int)blockIdx.x - (second ? n0 : 0));
+}
+
 // rows [32 rq, 32 rq + 32) of one tile of the pair update, S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' (grid = 4 nblk): the
 // row-split form of k_ldl_update<1> for SHORT updates.  A tile of the big kernel is bound by the matrix pipe of the four
 // waves that own it -- 1024 MFMAs per wave, ~30 us, however empty the chip is -- so an update of a few hundred tiles (the
@@ -893,14 +944,14 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs(T *__restrict__ S, const int
 // updated -- (rows[ii], rows[0]), ii = 0 .. lead_len-1, then (rows[ii], rows[1]), ii = 1 .. lead_len-1 -- what the next pair's
 // panel chain needs; the rest of the update runs beside that chain (dense_ldl_factor_sparse).
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_update_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
-                                                        const T *__restrict__ V1, int k, int base, int nblk,
-                                                        const int *__restrict__ rows, int lead_len = 0) {
+__device__ inline void ldl_update_rs_body(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
+                                          const T *__restrict__ V1, int k, int base, int nblk, const int *__restrict__ rows,
+                                          int lead_len, const int bid) {
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   T *lds = reinterpret_cast<T *>(smraw);
   T *sA = lds, *sB = lds + 2 * RS * LDK;
-  const int t = blockIdx.x >> 2, r0 = (blockIdx.x & 3) * RS;
+  const int t = bid >> 2, r0 = (bid & 3) * RS;
   if (t >= nblk) return;
   int ii, jj;
   if (lead_len > 0) {
@@ -933,6 +984,21 @@ __global__ __launch_bounds__(256) void k_ldl_update_rs(T *__restrict__ S, const 
         Sij[row * NB + col] -= acc[m][n][g];
       }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_update_rs(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
+                                                        const T *__restrict__ V1, int k, int base, int nblk,
+                                                        const int *__restrict__ rows, int lead_len = 0) {
+  ldl_update_rs_body<T>(S, co, V0, V1, k, base, nblk, rows, lead_len, (int)blockIdx.x);
+}
+// the pair updates of two runs in one launch (V: the run's first panel buffer, the second follows it at a panel's distance)
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_update_rs2(T *__restrict__ S, const int64_t *__restrict__ co, RunPanel<T> a, int nblk_a,
+                                                         RunPanel<T> c, int nblk_c, int64_t panel) {
+  const bool second = (int)blockIdx.x >= 4 * nblk_a;
+  const RunPanel<T> &r = second ? c : a;
+  ldl_update_rs_body<T>(S, co, r.V, r.V + panel, r.k, r.k + 2, second ? nblk_c : nblk_a, r.rows, 0, (int)blockIdx.x - (second ? 4 * nblk_a : 0));
 }
 
 // ---- fused panel-pair kernels (pair schedule) ------------------------------------------------------------------------------
@@ -1321,6 +1387,27 @@ __global__ __launch_bounds__(256) void k_ldl_update_part(T *__restrict__ S, cons
   }
 }
 
+// the pair updates of two runs in one launch, tile per workgroup (k_ldl_update's tile routine and enumeration over the run's
+// row list; the chunked block -> XCD map inside each run's part of the grid)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_ldl_update2(T *__restrict__ S, const int64_t *__restrict__ co, RunPanel<T> a, int nblk_a,
+                                                         RunPanel<T> c, int nblk_c, int64_t panel) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  const int ga = ((nblk_a + 7) / 8) * 8;
+  const bool second = (int)blockIdx.x >= ga;
+  const RunPanel<T> &r = second ? c : a;
+  const int nblk = second ? nblk_c : nblk_a, bid = (int)blockIdx.x - (second ? ga : 0);
+  const int per = (nblk + 7) / 8;
+  const int t = (bid & 7) * per + (bid >> 3);
+  if (t >= nblk) return;
+  int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+  while (ii * (ii + 1) / 2 > t) ii--;
+  const int jj = t - ii * (ii + 1) / 2;
+  ldl_update_tile<T>(S, co, r.V, r.V + panel, r.k, r.rows[ii], r.rows[jj], lds, nullptr, nullptr);
+}
+
 // ---- distributed factorisation helpers -----------------------------------------------------------------------------------
 // A rank that received the panel V = L D of tile column k from its owner rebuilds L_ik = V_i D_k^-1 in its own copy of S
 // (rows i0..nt-1), with the owner's arithmetic (k_ldl_trsm_rs: xv * (1 / d)), so that every rank holds the same bits.
@@ -1506,6 +1593,10 @@ static int set_kernel_attrs() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PT_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_rs<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RS_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)gemm_priv_lds_bytes<T>()));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_diag2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(DIAG_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_part<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, true>),
@@ -1976,11 +2067,12 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
   const int nt = (int)w->nt;
   const TilePattern *pat = w->pat;
   const int64_t panel = (int64_t)nt * NB * NB;
+  const int npairs = (nt + 1) / 2;
   T *y = w->D + w->nt * NB;
   w->hoisting = false;
   const char *la_env = getenv("BA_SPARSE_LOOKAHEAD");  // read per call: tests compare both schedules in one process
   const bool lookahead = !p->prof_on && !(la_env && la_env[0] == '0');
-  const int la_min = [] { const char *e = getenv("BA_SPARSE_LOOKAHEAD_MIN"); return e ? atoi(e) : 256; }();  // (read per call: the tests force it to 1)   // tiles of a rest worth a fork (below: one launch on the main stream, as before)
+  const int la_min = [] { const char *e = getenv("BA_SPARSE_LOOKAHEAD_MIN"); return e ? atoi(e) : 256; }();  // (read per call: the tests force it to 1) 
   static const int rest_cus = [] { const char *e = getenv("BA_SPARSE_REST_CUS"); return e ? atoi(e) : 192; }();  // CUs the rest may take
   bool pending[2] = {false, false};  // rest of pair q (slot q & 1) launched on the second stream and not yet joined
   auto join_rest = [&](int slot) -> int {
@@ -2002,51 +2094,117 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
                          w->col_off, V0, V1, k, k + 2, nt, nblk, (int *)nullptr, (const int *)nullptr, (const int64_t *)nullptr, 0, 0,
                          1, rows);
   };
-  for (int k = 0, q = 0; k < nt; k += 2, q++) {
-    const int slot = q & 1;
-    T *V0 = w->V + 2 * slot * panel, *V1 = V0 + panel;
+  // the panel chain of pair q on stream s: diag(k), panel solve over {k+1} + U_q, column update, diag(k+1), panel solve over U_q
+  // (+ the forward substitution of d_b).  Returns the number of rows of U_q whose trailing update is still to do (0: none).
+  auto chain = [&](int q, hipStream_t s, T *V0, T *V1, bool clear_flag) -> int {
+    const int k = 2 * q;
     const int l0 = pat->prow_ptr[(size_t)q], l1 = pat->prow_ptr[(size_t)q + 1];
     const int c1 = l1 - l0;                      // {k+1} + U_q
     const int c2 = c1 > 0 ? c1 - 1 : 0;          // U_q
     const int *rows1 = w->prow + l0, *rows2 = w->prow + l0 + 1;
-    BA_CHECK(join_rest(slot));  // (the rest of pair q-2 read these panel buffers; joined long ago: see lead below)
-    launch_diag(p, w, k, st, nullptr, k == 0);  // (the first one clears the pivot flag)
+    launch_diag(p, w, k, s, nullptr, clear_flag);
     if (c1 == 0) {  // last, single tile column: y_k only
-      if (d_b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k, (const int *)nullptr);
-      break;
+      if (d_b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, s, w->S, w->col_off, w->Linv, d_b, y, k, (const int *)nullptr);
+      return 0;
     }
     {
-      ProfScope ps(p, PC_LDL_TRSM, st);
+      ProfScope ps(p, PC_LDL_TRSM, s);
       if (d_b)
-        hipLaunchKernelGGL((k_ldl_trsm_rs<T, true>), dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, true>), dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), s, w->S, w->col_off,
                            w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, V0, k, d_b, y, rows1);
       else
-        hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), s, w->S, w->col_off,
                            w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, V0, k, d_b, y, rows1);
     }
     {
-      ProfScope ps(p, PC_LDL_SYRK, st);
-      hipLaunchKernelGGL(k_ldl_col_rs<T>, dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, V0, k, rows1);
+      ProfScope ps(p, PC_LDL_SYRK, s);
+      hipLaunchKernelGGL(k_ldl_col_rs<T>, dim3(4 * c1), dim3(256), RS_LDS_ELEMS * sizeof(T), s, w->S, w->col_off, V0, k, rows1);
     }
-    launch_diag(p, w, k + 1, st);
+    launch_diag(p, w, k + 1, s);
     if (c2 == 0) {
-      if (d_b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, st, w->S, w->col_off, w->Linv, d_b, y, k + 1, (const int *)nullptr);
-      continue;
+      if (d_b) hipLaunchKernelGGL(k_fwd_step<T>, dim3(1), dim3(256), 0, s, w->S, w->col_off, w->Linv, d_b, y, k + 1, (const int *)nullptr);
+      return 0;
     }
     {
-      ProfScope ps(p, PC_LDL_TRSM, st);
+      ProfScope ps(p, PC_LDL_TRSM, s);
       if (d_b)
-        hipLaunchKernelGGL((k_ldl_trsm_rs<T, true>), dim3(4 * c2), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, true>), dim3(4 * c2), dim3(256), RS_LDS_ELEMS * sizeof(T), s, w->S, w->col_off,
                            w->Linv + (int64_t)(k + 1) * NB * NB, w->D + (int64_t)(k + 1) * NB, V1, k + 1, d_b, y, rows2);
       else
-        hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * c2), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off,
+        hipLaunchKernelGGL((k_ldl_trsm_rs<T, false>), dim3(4 * c2), dim3(256), RS_LDS_ELEMS * sizeof(T), s, w->S, w->col_off,
                            w->Linv + (int64_t)(k + 1) * NB * NB, w->D + (int64_t)(k + 1) * NB, V1, k + 1, d_b, y, rows2);
     }
+    return c2;
+  };
+  // Two runs (TilePattern::a_clean / b_clean: the ordering eliminated a profile from both ends, ba_order.cpp): the first
+  // a_clean pairs and the b_clean pairs from `split` touch disjoint tiles, rows of the right-hand side and panel buffers
+  // (slot 0 / slot 1).  They advance together, pair i of either run in the SAME launches ("two runs per launch" above): one
+  // stream, no event, half the launches -- the kernels of a panel chain are a workgroup or a few dozen each and the latency of
+  // a launch with two panels' worth of them is that of one.  The longer run finishes alone; every other pair follows below in
+  // index order.  Each tile still receives its updates in ascending pair order WITHIN a run; the frontier's tiles receive the
+  // second run's updates before the late pairs of the first -- a different but fixed summation order
+  // (BA_SPARSE_TWO_RUNS=0: one chain; never with per-kernel profiling, whose classes time single-run launches).
+  const char *tc_env = getenv("BA_SPARSE_TWO_RUNS");
+  const bool two = pat->a_clean > 0 && pat->b_clean > 0 && !p->prof_on && !(tc_env && tc_env[0] == '0');
+  std::vector<int> order;
+  if (two) {
+    BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));  // (no diagonal kernel of the two runs clears the pivot flag)
+    T *VA = w->V, *VB = w->V + 2 * panel;
+    const int both = std::min(pat->a_clean, pat->b_clean);
+    for (int i = 0; i < both; i++) {
+      const int qa = i, qb = pat->split + i, ka = 2 * qa, kb = 2 * qb;
+      const int la = pat->prow_ptr[(size_t)qa], lb = pat->prow_ptr[(size_t)qb];
+      const int c1a = pat->prow_ptr[(size_t)qa + 1] - la, c1b = pat->prow_ptr[(size_t)qb + 1] - lb;  // {k+1} + U_q: >= 2 inside a run
+      const int c2a = c1a - 1, c2b = c1b - 1;
+      auto tile = [&](int k) { return w->S + tix(w->hco(), k, k) * NB * NB; };
+      auto panel_of = [&](int k, T *V, const int *rows) { return RunPanel<T>{w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, V, k, rows}; };
+      hipLaunchKernelGGL(k_ldl_diag2<T>, dim3(2), dim3(DIAG_THREADS), DIAG_LDS_ELEMS * sizeof(T), st, tile(ka), w->Linv + (int64_t)ka * NB * NB,
+                         w->D + (int64_t)ka * NB, tile(kb), w->Linv + (int64_t)kb * NB * NB, w->D + (int64_t)kb * NB, w->flag);
+      const RunPanel<T> a0 = panel_of(ka, VA, w->prow + la), b0 = panel_of(kb, VB, w->prow + lb);
+      if (d_b)
+        hipLaunchKernelGGL((k_ldl_trsm_rs2<T, true>), dim3(4 * (c1a + c1b)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, a0, b0, 4 * c1a, d_b, y);
+      else
+        hipLaunchKernelGGL((k_ldl_trsm_rs2<T, false>), dim3(4 * (c1a + c1b)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, a0, b0, 4 * c1a, d_b, y);
+      hipLaunchKernelGGL(k_ldl_col_rs2<T>, dim3(4 * (c1a + c1b)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, a0, b0, 4 * c1a);
+      hipLaunchKernelGGL(k_ldl_diag2<T>, dim3(2), dim3(DIAG_THREADS), DIAG_LDS_ELEMS * sizeof(T), st, tile(ka + 1),
+                         w->Linv + (int64_t)(ka + 1) * NB * NB, w->D + (int64_t)(ka + 1) * NB, tile(kb + 1), w->Linv + (int64_t)(kb + 1) * NB * NB,
+                         w->D + (int64_t)(kb + 1) * NB, w->flag);
+      const RunPanel<T> a1 = panel_of(ka + 1, VA + panel, w->prow + la + 1), b1 = panel_of(kb + 1, VB + panel, w->prow + lb + 1);
+      if (d_b)
+        hipLaunchKernelGGL((k_ldl_trsm_rs2<T, true>), dim3(4 * (c2a + c2b)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, a1, b1, 4 * c2a, d_b, y);
+      else
+        hipLaunchKernelGGL((k_ldl_trsm_rs2<T, false>), dim3(4 * (c2a + c2b)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, a1, b1, 4 * c2a, d_b, y);
+      // the two pair updates: panels (k, k+1) of either run over its U_q
+      const RunPanel<T> ua = panel_of(ka, VA, w->prow + la + 1), ub = panel_of(kb, VB, w->prow + lb + 1);
+      const int na = c2a * (c2a + 1) / 2, nb2 = c2b * (c2b + 1) / 2;
+      if (na + nb2 <= update_rs_max())
+        hipLaunchKernelGGL(k_ldl_update_rs2<T>, dim3(4 * (na + nb2)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, ua, na, ub, nb2, panel);
+      else
+        hipLaunchKernelGGL(k_ldl_update2<T>, dim3(((na + 7) / 8) * 8 + ((nb2 + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S, w->col_off,
+                           ua, na, ub, nb2, panel);
+    }
+    BA_HIP_CHECK(hipGetLastError());
+    for (int q = both; q < pat->a_clean; q++) order.push_back(q);  // the longer run's remainder, then everything else
+    for (int q = pat->a_clean; q < pat->split; q++) order.push_back(q);
+    for (int q = pat->split + both; q < npairs; q++) order.push_back(q);
+  } else {
+    for (int q = 0; q < npairs; q++) order.push_back(q);
+  }
+  for (size_t it = 0; it < order.size(); it++) {
+    const int q = order[it], k = 2 * q;
+    const int slot = (int)(it & 1);
+    T *V0 = w->V + 2 * slot * panel, *V1 = V0 + panel;
+    const int l0 = pat->prow_ptr[(size_t)q];
+    const int *rows2 = w->prow + l0 + 1;
+    BA_CHECK(join_rest(slot));  // (the rest of the pair two steps back read these panel buffers; joined long ago: see lead below)
+    const int c2 = chain(q, st, V0, V1, !two && q == 0);  // (in one chain the first diagonal kernel clears the pivot flag)
+    if (c2 == 0) continue;
     // the rows of U_q that are the next pair's own tile columns (k+2, k+3): at the head of the ascending list
+    const bool next_adjacent = it + 1 < order.size() && order[it + 1] == q + 1;
     int nlead = 0;
     while (nlead < c2 && nlead < 2 && pat->prow[(size_t)(l0 + 1 + nlead)] < k + 4) nlead++;
     const int nrest = c2 - nlead;
-    if (lookahead && nrest * (nrest + 1) / 2 >= la_min) {
+    if (lookahead && next_adjacent && nrest * (nrest + 1) / 2 >= la_min) {
       // the lead first, alone on the chip (beside the rest it takes as long as the whole update: measured), then the rest
       // beside the next chain
       BA_CHECK(join_rest(slot ^ 1));  // rest(q-1) has updated the lead tiles too (and the next chain reads its columns)

@@ -207,6 +207,7 @@ struct LMWorkFull : LMWork {
   int order_method = BA_ORDER_AMD;
   std::vector<int> h_cam_perm;
   const char *order_name = "natural";
+  int order_split = 0;  // the sequence eliminates from both ends: tile column pair at which the second run starts (0: one run)
   // facto_type = Float32 (src/lm.jl:170-173): Float32 copy of the reduced camera system, allocated on first use
   DenseLDLT<float> ldl32;
   float *rhs32 = nullptr;
@@ -616,6 +617,7 @@ static int order_cameras(ba_problem *p, LMWorkFull *w, std::vector<int> *pos_out
   pos_out->clear();
   w->h_cam_perm.clear();
   w->order_name = "natural";
+  w->order_split = 0;
   int method = w->order_method;
   if (const char *e = getenv("BA_CAM_ORDER")) {  // amd | metis | natural: overrides the handle's setting (experiments)
     method = e[0] == 'n' ? BA_ORDER_NATURAL : (e[0] == 'm' ? BA_ORDER_METIS : BA_ORDER_AMD);
@@ -632,11 +634,13 @@ static int order_cameras(ba_problem *p, LMWorkFull *w, std::vector<int> *pos_out
   if ((double)g.edges() > 0.25 * (double)n * (double)(n - 1)) return BA_OK;
   std::vector<int> perm;
   const char *name = "natural";
-  cam_order(g, method, NB, &perm, &name);
+  int split = 0;
+  cam_order(g, method, NB, &perm, &name, &split);
   bool identity = true;
   for (int64_t k = 0; k < n && identity; k++) identity = perm[(size_t)k] == (int)k;
   if (identity) return BA_OK;
   w->order_name = name;
+  w->order_split = split;
   pos_out->resize((size_t)n);
   for (int64_t k = 0; k < n; k++) (*pos_out)[(size_t)perm[(size_t)k]] = (int)k;
   BA_CHECK(upload_vec(&w->tasks.cam_of, perm));
@@ -657,7 +661,7 @@ static int ensure_dense(ba_problem *p, LMWorkFull *w) {
   // off).  Every camera pair sharing points (the default synthetic generator, small problems) gives flop_fill = 1: dense.
   // several ranks: a rank's keys only show the tiles ITS observations touch; the pattern is that of the sum
   if (dist_factor_on(p)) BA_CHECK(allreduce_flags(p, &w->tasks.tile_occ));
-  tile_pattern_build(w->ldl.nt, w->tasks.tile_occ, &w->pattern);
+  tile_pattern_build(w->ldl.nt, w->tasks.tile_occ, &w->pattern, w->order_split);
   w->tasks.tile_occ.clear();
   w->tasks.tile_occ.shrink_to_fit();
   const char *e = getenv("BA_SPARSE_S");

@@ -23,7 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <numeric>
+#include <numeric>  // std::iota, std::gcd
 
 namespace {
 
@@ -406,6 +406,10 @@ double tile_pattern_cost(const TilePattern &pat) {
     const double c1 = (double)(pat.prow_ptr[q + 1] - pat.prow_ptr[q]), u = c1 > 0 ? c1 - 1 : 0;
     cost += std::max(u * (u + 1) / 2, 256.0) + 8.0 * u;
   }
+  // ... and the chain: a pair's two diagonal tiles, panel solves and column update cost what ~640 update tiles cost
+  // (~100 us against 0.15 us per tile) whatever its row list; pairs of two independent runs share that time
+  const double npairs = (double)pat.prow_ptr.size() - 1.0;
+  cost += 640.0 * (npairs - (double)std::min(pat.a_clean, pat.b_clean));
   return cost;
 }
 
@@ -416,20 +420,22 @@ double tile_pattern_cost(const TilePattern &pat) {
 // deferred to the end (or none); then minimum degree for :AMD, nested dissection for :Metis.  At BAL sizes (10^2..10^4
 // cameras, 14 of them per tile) profile-reducing sequences usually win: the unit of fill is a 128 x 128 tile, and scattered
 // scalar fill costs whole tiles.
-void cam_order(const CamGraph &g, int method, int nb, std::vector<int> *perm, const char **chosen) {
+void cam_order(const CamGraph &g, int method, int nb, std::vector<int> *perm, const char **chosen, int *split_pair) {
   const int64_t n = g.n;
   perm->resize((size_t)n);
   std::iota(perm->begin(), perm->end(), 0);
   if (chosen) *chosen = "natural";
+  if (split_pair) *split_pair = 0;
   if (method == BA_ORDER_NATURAL || n < 2) return;
   const int64_t nt = std::max<int64_t>(1, (9 * n + nb - 1) / nb);
   std::vector<int> pos((size_t)n), cand;
   std::vector<unsigned char> occ;
   TilePattern pat;
+  int cand_split = 0;  // split hint of the candidate being offered
   auto cost_of = [&](const std::vector<int> &order) {
     for (int64_t k = 0; k < n; k++) pos[(size_t)order[(size_t)k]] = (int)k;
     cam_tile_occupancy(g, pos, nt, nb, &occ);
-    tile_pattern_build(nt, occ, &pat);
+    tile_pattern_build(nt, occ, &pat, cand_split);
     return tile_pattern_cost(pat);
   };
   const bool verbose = getenv("BA_ORDER_VERBOSE") != nullptr;
@@ -442,6 +448,7 @@ void cam_order(const CamGraph &g, int method, int nb, std::vector<int> *perm, co
       best = c;
       *perm = cand;
       if (chosen) *chosen = name;
+      if (split_pair) *split_pair = (pat.a_clean > 0 && pat.b_clean > 0) ? cand_split : 0;
     }
   };
   std::vector<int> deg((size_t)n, 0), sorted;
@@ -498,6 +505,37 @@ void cam_order(const CamGraph &g, int method, int nb, std::vector<int> *perm, co
       for (int c : members[(size_t)gi]) cand.push_back(c);
     offer(method == BA_ORDER_AMD ? "minimum-degree on tile pairs" : "nested-dissection on tile pairs");
   }
+  // ... and the best sequence eliminated FROM BOTH ENDS: the first m cameras (A), then the cameras behind them that are not
+  // adjacent to A, LAST FIRST (B, from the far end inwards), then the frontier between the two (S).  A and B share no edge, so
+  // their tile column pairs factor side by side as two chains of half the length, and a profile-ordered sequence pays no fill
+  // for it (a band eliminated from both ends fills its band, as from one end).  m is a multiple of 256 cameras: only there does
+  // a camera boundary (9 rows) coincide with a tile-pair boundary (2 nb rows), and B must start on one.
+  {
+    const std::vector<int> base = *perm;
+    const int64_t unit = 2 * (int64_t)nb / std::gcd((int64_t)9, 2 * (int64_t)nb) ;  // cameras per common boundary (256 for nb = 128)
+    const int64_t m = (n / 2 / unit) * unit;
+    if (m >= unit && n - m >= 2 * unit) {
+      std::vector<char> inA((size_t)n, 0), inS((size_t)n, 0);
+      for (int64_t k = 0; k < m; k++) inA[(size_t)base[(size_t)k]] = 1;
+      for (int64_t k = m; k < n; k++) {
+        const int c = base[(size_t)k];
+        bool adj = false;
+        for_bits(&g.bits[(size_t)((int64_t)c * g.W)], g.W, [&](int u) { adj |= inA[(size_t)u] != 0; });
+        inS[(size_t)c] = adj;
+      }
+      cand.assign(base.begin(), base.begin() + m);
+      for (int64_t k = n - 1; k >= m; k--)
+        if (!inS[(size_t)base[(size_t)k]]) cand.push_back(base[(size_t)k]);
+      const int64_t nB = (int64_t)cand.size() - m;
+      for (int64_t k = m; k < n; k++)
+        if (inS[(size_t)base[(size_t)k]]) cand.push_back(base[(size_t)k]);
+      if (nB >= unit) {
+        cand_split = (int)(9 * m / (2 * (int64_t)nb));
+        offer("two-ended");
+        cand_split = 0;
+      }
+    }
+  }
 }
 
 void cam_tile_occupancy(const CamGraph &g, const std::vector<int> &pos, int64_t nt, int nb, std::vector<unsigned char> *occ) {
@@ -521,7 +559,8 @@ void cam_tile_occupancy(const CamGraph &g, const std::vector<int> &pos, int64_t 
 // with a pattern tile in either column, and every tile (i, j), i >= j, i, j in U_q, joins the pattern (fill).  Taking the
 // union of the two columns' rows keeps ONE row list per pair; a tile whose operands are structurally zero receives a zero
 // update (correct, a little wasted work when the two columns differ).  Counterpart of src/ldl_aux.jl:82-119.
-void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ /* nt x nt, lower, row-major; gets the fill */, TilePattern *out) {
+void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ /* nt x nt, lower, row-major; gets the fill */, TilePattern *out,
+                        int split_pair) {
   const int npairs = (int)((nt + 1) / 2);
   out->nt = nt;
   out->prow_ptr.assign(1, 0);
@@ -570,6 +609,32 @@ void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ /* nt x nt, 
   }
   out->tile_fill = (double)(ntiles + nt) / ((double)nt * (double)(nt + 1) / 2);
   out->flop_fill = tiles_dense > 0 ? tiles_sparse / tiles_dense : 1.0;
+  // two chains: the longest run of pairs from 0 whose rows stay below the split (nothing of theirs touches the second group),
+  // and the longest run from the split whose own columns no pair of the first group touches (what the late pairs of the first
+  // group still update -- the frontier -- must not have been eliminated yet)
+  out->split = out->a_clean = out->b_clean = 0;
+  if (split_pair > 0 && split_pair < npairs) {
+    const int a = split_pair;
+    std::vector<unsigned char> dirty((size_t)nt, 0);  // tile rows >= 2a that a pair of the first group touches
+    int ac = -1;
+    for (int q = 0; q < a; q++) {
+      bool clean = true;
+      for (int l = out->prow_ptr[(size_t)q]; l < out->prow_ptr[(size_t)q + 1]; l++)
+        if (out->prow[(size_t)l] >= 2 * a) {
+          dirty[(size_t)out->prow[(size_t)l]] = 1;
+          clean = false;
+        }
+      if (!clean && ac < 0) ac = q;
+    }
+    if (ac < 0) ac = a;
+    int bc = 0;
+    while (a + bc < npairs && !dirty[(size_t)(2 * (a + bc))] && (2 * (a + bc) + 1 >= nt || !dirty[(size_t)(2 * (a + bc) + 1)])) bc++;
+    if (std::min(ac, bc) >= 4) {
+      out->split = a;
+      out->a_clean = ac;
+      out->b_clean = bc;
+    }
+  }
 }
 
 // From the index arrays of a BAL problem (1-based, any observation order): camera ordering by `method`, and the fill of the
@@ -591,14 +656,15 @@ int schur_ordering_host(int64_t ncams, int64_t npnts, int64_t nobs, const int64_
   CamGraph g;
   cam_graph_build(ncams, npnts, ptr.data(), obs.data(), cam0.data(), &g);
   std::vector<int> perm, pos((size_t)ncams);
-  cam_order(g, method, nb, &perm, nullptr);
+  int split = 0;
+  cam_order(g, method, nb, &perm, nullptr, &split);
   if ((int64_t)perm.size() != ncams) return 2;
   for (int64_t k = 0; k < ncams; k++) pos[(size_t)perm[(size_t)k]] = (int)k;
   const int64_t nt = std::max<int64_t>(1, (9 * ncams + nb - 1) / nb);
   std::vector<unsigned char> occ;
   cam_tile_occupancy(g, pos, nt, nb, &occ);
   TilePattern pat;
-  tile_pattern_build(nt, occ, &pat);
+  tile_pattern_build(nt, occ, &pat, split);
   if (perm1)
     for (int64_t k = 0; k < ncams; k++) perm1[k] = perm[(size_t)k] + 1;
   if (tile_fill) *tile_fill = pat.tile_fill;

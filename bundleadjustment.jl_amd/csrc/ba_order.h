@@ -16,10 +16,16 @@ struct TilePattern {
   std::vector<int> lpair_ptr, lpair;  // launch q of the paired backward sweep (rows k = nt-1-2q, k-1): union of their columns < k-1
   double tile_fill = 1.0;           // pattern tiles (with fill) / all lower tiles
   double flop_fill = 1.0;           // trailing-update tiles of the pattern / of the dense factorisation
+  // Two independent chains (elimination from both ends of a profile-ordered sequence, see cam_order): the pairs [0, a_clean)
+  // and [split, split + b_clean) touch disjoint tiles and no other pair before `split` touches the second group's columns, so
+  // the two runs may factor side by side; all other pairs follow in index order.  0 / 0: one chain.
+  int split = 0, a_clean = 0, b_clean = 0;
 };
 
 // symbolic factorisation of the tile occupancy `occ` (nt x nt, lower, row-major; receives the fill) per tile column pair
-void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ, TilePattern *out);
+// split_pair > 0: the tile column pair at which a second, independent group of columns starts (hint from the ordering; what can
+// really run side by side is worked out from the pattern: TilePattern::a_clean, b_clean)
+void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ, TilePattern *out, int split_pair = 0);
 
 // camera graph: cameras adjacent when they share a point; one bit row per camera (no self loops)
 struct CamGraph {
@@ -34,7 +40,8 @@ void cam_graph_build(int64_t ncams, int64_t npnts, const int *pt_ptr, const int 
 
 // position -> camera ("perm[k] is the camera at block row k of S"); method BA_ORDER_*; nb = tile size in scalars.
 // Deterministic.  chosen (optional): name of the candidate sequence that won (static storage).
-void cam_order(const CamGraph &g, int method, int nb, std::vector<int> *perm, const char **chosen);
+// split_pair (optional): see tile_pattern_build
+void cam_order(const CamGraph &g, int method, int nb, std::vector<int> *perm, const char **chosen, int *split_pair = nullptr);
 double tile_pattern_cost(const TilePattern &pat);
 
 // tile occupancy (nt x nt lower, before fill) of S when camera c sits at block row pos[c]; NB = tile size in scalars

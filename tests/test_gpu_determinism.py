@@ -69,6 +69,54 @@ def test_lm_step_twice_same_bits_venice_scaled(ba, gpu_ok):
 
 
 
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_block_sparse_two_chains(ba, orc, gpu_ok, shuffle):
+    """A profile eliminated from both ends (ba_order.cpp: "two-ended"): the list schedule runs the two independent runs of tile
+    column pairs together, pair i of either run in the same launches (dense_ldl_factor_sparse, "two runs per launch"), and the
+    remaining pairs in order.  1 100 cameras (n =
+    9 900, 78 tile rows), cameras of a point within 10 % of the cameras, as generated and renumbered at random: the sequence
+    chosen is the two-ended one, the pattern reports two runs, the step equals the oracle's (its ldl_analyse handed the same
+    camera sequence) to 1e-9 and the one-chain schedule's (BA_SPARSE_TWO_RUNS=0) to 1e-11, Float32 to Float32 level; the
+    same bits twice, and recorded graphs = plain launches."""
+    p = ba.synthetic.make_problem(1100, 6000, 30000, seed=35, locality=0.1)
+    if shuffle:
+        p, _ = ba.synthetic.shuffle_cameras(p, seed=8)
+    arrays = ba.synthetic.as_arrays(p)
+
+    def step(facto_type=None):
+        m = ba.BALNLPModel(arrays=arrays)
+        d1, h1, _ = ba.lm_step(m, p["x0"], 10.0, facto_type=facto_type)
+        d2, h2, _ = ba.lm_step(m, p["x0"], 10.0, facto_type=facto_type)
+        pat, (perm, name) = ba.schur_pattern(m), ba.schur_ordering_used(m)
+        m.close()
+        return d1, d2, h1, h2, pat, perm, name
+
+    a1, a2, ha1, ha2, pat, perm, name = step()
+    b1, _, hb1, _, _, _, _ = _env("BA_SPARSE_TWO_RUNS", "0", step)
+    f1, f2, _, _, _, _, _ = step(np.float32)
+    assert name == "two-ended" and pat[2], (name, pat)
+    rc, d_ref, dr_ref, _ = orc.lm_step(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"], 10.0, cam_perm1=perm)
+    assert rc == 0
+    e_orc, e_one, e32 = rel_err(a1, d_ref), rel_err(a1, b1), rel_err(f1, d_ref)
+    print(f"two chains ({'shuffled' if shuffle else 'as generated'}): vs oracle {e_orc:.2e}, vs one chain {e_one:.2e}, Float32 vs oracle {e32:.2e}; pattern {pat}")
+    assert e_orc <= 1e-9 and e_one <= 1e-11 and e32 <= 5e-3
+    assert abs(ha1 - 0.5 * float(dr_ref @ dr_ref)) <= 1e-10 * ha1 and ha1 == ha2
+    for tag, (x, y) in {"Float64 step twice": (a1, a2), "Float32-factor step twice": (f1, f2)}.items():
+        rep = bits_report(x, y, tag)
+        assert not rep, rep
+
+    def run(graph):
+        m = ba.BALNLPModel(arrays=arrays)
+        st = _env("BA_LM_GRAPH", graph, lambda: ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "LDL", "AMD", "None", False, ite_max=4))
+        m.close()
+        return st
+
+    s_graph, s_plain = run(None), run("0")
+    assert s_graph.iter == s_plain.iter and s_graph.log == s_plain.log
+    rep = bits_report(s_graph.solution, s_plain.solution, "solution of a 5-iteration run, recorded graphs vs plain launches")
+    assert not rep, rep
+
+
 def test_lm_solve_with_the_iterate_on_the_device_same_bits(ba, gpu_ok):
     """ba_lm_solve_dev (the iterate resident in device memory: what bench.py times) against ba_lm_solve (host vectors, the
     reference's boundary): same iterations, status, log rows and the same bits in the solution."""
