@@ -995,10 +995,12 @@ __global__ __launch_bounds__(256) void k_ldl_update_rs(T *__restrict__ S, const 
 // the pair updates of two runs in one launch (V: the run's first panel buffer, the second follows it at a panel's distance)
 template <typename T>
 __global__ __launch_bounds__(256) void k_ldl_update_rs2(T *__restrict__ S, const int64_t *__restrict__ co, RunPanel<T> a, int nblk_a,
-                                                         RunPanel<T> c, int nblk_c, int64_t panel) {
+                                                         RunPanel<T> c, int nblk_c, int64_t panel, int lead_a = 0, int lead_c = 0) {
+  // lead_a / lead_c > 0: the run's launch part is the lead strip of its look-ahead (see k_ldl_update_rs)
   const bool second = (int)blockIdx.x >= 4 * nblk_a;
   const RunPanel<T> &r = second ? c : a;
-  ldl_update_rs_body<T>(S, co, r.V, r.V + panel, r.k, r.k + 2, second ? nblk_c : nblk_a, r.rows, 0, (int)blockIdx.x - (second ? 4 * nblk_a : 0));
+  ldl_update_rs_body<T>(S, co, r.V, r.V + panel, r.k, r.k + 2, second ? nblk_c : nblk_a, r.rows, second ? lead_c : lead_a,
+                        (int)blockIdx.x - (second ? 4 * nblk_a : 0));
 }
 
 // ---- fused panel-pair kernels (pair schedule) ------------------------------------------------------------------------------
@@ -1387,6 +1389,24 @@ __global__ __launch_bounds__(256) void k_ldl_update_part(T *__restrict__ S, cons
   }
 }
 
+// k_ldl_update_part for two runs: the rests of both runs' updates walked by one set of persistent workgroups
+template <typename T>
+__global__ __launch_bounds__(256) void k_ldl_update_part2(T *__restrict__ S, const int64_t *__restrict__ co, RunPanel<T> a, int nblk_a,
+                                                           RunPanel<T> c, int nblk_c, int64_t panel) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  T *lds = reinterpret_cast<T *>(smraw);
+  for (int tt = blockIdx.x; tt < nblk_a + nblk_c; tt += gridDim.x) {
+    const bool second = tt >= nblk_a;
+    const RunPanel<T> &r = second ? c : a;
+    const int t = tt - (second ? nblk_a : 0);
+    int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+    while (ii * (ii + 1) / 2 > t) ii--;
+    const int jj = t - ii * (ii + 1) / 2;
+    ldl_update_tile<T>(S, co, r.V, r.V + panel, r.k, r.rows[ii], r.rows[jj], lds, nullptr, nullptr);
+  }
+}
+
 // the pair updates of two runs in one launch, tile per workgroup (k_ldl_update's tile routine and enumeration over the run's
 // row list; the chunked block -> XCD map inside each run's part of the grid)
 template <typename T>
@@ -1597,6 +1617,8 @@ static int set_kernel_attrs() {
                                    (int)gemm_priv_lds_bytes<T>()));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_diag2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(DIAG_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_part2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)PART_LDS_BYTES));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_part<T>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, true>),
@@ -1666,7 +1688,7 @@ int dense_ldl_alloc(DenseLDLT<T> *w, int64_t n_unpadded, T *external_S, int worl
     BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)w->s_tiles * NB * NB * sizeof(T)));
     w->own_S = true;
   }
-  if (!lazy_S) BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * nt * NB * NB * sizeof(T)));  // 2 x two panels of L*D
+  if (!lazy_S) BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)8 * nt * NB * NB * sizeof(T)));  // (two runs) x (two slots) x two panels of L*D
   if (!lazy_S && w->own_only) {
     BA_HIP_CHECK(hipMalloc((void **)&w->Lb, (size_t)4 * nt * NB * NB * sizeof(T)));  // their L = V D^-1
     BA_HIP_CHECK(hipMalloc((void **)&w->bpart, (size_t)2 * nt * NB * sizeof(T)));
@@ -1703,7 +1725,7 @@ int dense_ldl_alloc_S(DenseLDLT<T> *w) {
     BA_HIP_CHECK(hipMalloc((void **)&w->S, (size_t)w->s_tiles * NB * NB * sizeof(T)));
     w->own_S = true;
   }
-  if (!w->V) BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)4 * w->nt * NB * NB * sizeof(T)));
+  if (!w->V) BA_HIP_CHECK(hipMalloc((void **)&w->V, (size_t)8 * w->nt * NB * NB * sizeof(T)));
   if (!w->Lb && w->own_only) BA_HIP_CHECK(hipMalloc((void **)&w->Lb, (size_t)4 * w->nt * NB * NB * sizeof(T)));
   if (!w->bpart && w->own_only) BA_HIP_CHECK(hipMalloc((void **)&w->bpart, (size_t)2 * w->nt * NB * sizeof(T)));
   return BA_OK;
@@ -2058,10 +2080,10 @@ int dense_ldl_use_pattern(DenseLDLT<T> *w, const TilePattern *pat) {
 // What it buys (kernel trace, Final-13682 shape with 6 % tile fill, Float32): the in-order pair takes 137 us -- diag 28,
 // solve 11, column 8, diag 28, solve 11, update 53; with the look-ahead the 48 us rest disappears behind the next chain, the
 // 12 us lead stays, and every fork / join of the replayed graph costs ~12 us of cross-queue synchronisation: 131 us per pair,
-// 101 -> 93 ms per LM iteration.  Rests shorter than BA_SPARSE_LOOKAHEAD_MIN tiles (256: the Venice shape's are 120) are
-// not worth their two synchronisations and stay in order.  What would shorten the chain itself -- independent subtrees of
-// the elimination tree on several streams -- needs per-subtree contribution blocks for the separator tiles (two subtrees
-// update the same tiles): not built.
+// 101 -> 93 ms per LM iteration.  Rests shorter than BA_SPARSE_LOOKAHEAD_MIN tiles stay in order: 96 (sweep on the Venice shape
+// with locality 0.13, whose rests are 120 tiles, two runs per launch: 16 / 48 / 96 / 160 / 256 -> 11.8 / 11.8 / 11.8 / 12.7 /
+// 12.7 ms; the Final shape is indifferent).  What shortens the chain itself: two independent runs of pairs advancing in
+// the same launches, below ("Two runs").
 template <typename T>
 int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int *zero_pivot, T *d_b) {
   const int nt = (int)w->nt;
@@ -2072,8 +2094,8 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
   w->hoisting = false;
   const char *la_env = getenv("BA_SPARSE_LOOKAHEAD");  // read per call: tests compare both schedules in one process
   const bool lookahead = !p->prof_on && !(la_env && la_env[0] == '0');
-  const int la_min = [] { const char *e = getenv("BA_SPARSE_LOOKAHEAD_MIN"); return e ? atoi(e) : 256; }();  // (read per call: the tests force it to 1) 
-  static const int rest_cus = [] { const char *e = getenv("BA_SPARSE_REST_CUS"); return e ? atoi(e) : 192; }();  // CUs the rest may take
+  const int la_min = [] { const char *e = getenv("BA_SPARSE_LOOKAHEAD_MIN"); return e ? atoi(e) : 96; }();  // (read per call: the tests force it to 1)
+  static const int rest_cus = [] { const char *e = getenv("BA_SPARSE_REST_CUS"); return e ? atoi(e) : 224; }();  // CUs the rest may take (sweep: 128 / 192 / 224 -> 76.1 / 71.9 / 71.3 ms on the Final shape)
   bool pending[2] = {false, false};  // rest of pair q (slot q & 1) launched on the second stream and not yet joined
   auto join_rest = [&](int slot) -> int {
     if (pending[slot]) {
@@ -2149,15 +2171,18 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
   std::vector<int> order;
   if (two) {
     BA_HIP_CHECK(hipMemsetAsync(w->flag, 0, sizeof(int), st));  // (no diagonal kernel of the two runs clears the pivot flag)
-    T *VA = w->V, *VB = w->V + 2 * panel;
     const int both = std::min(pat->a_clean, pat->b_clean);
     for (int i = 0; i < both; i++) {
+      const int slot = i & 1;
+      // panel buffers: run A takes panels 0..3 (two slots of two), run B panels 4..7; the slots alternate for the look-ahead
+      T *VA = w->V + 2 * slot * panel, *VB = w->V + (4 + 2 * slot) * panel;
       const int qa = i, qb = pat->split + i, ka = 2 * qa, kb = 2 * qb;
       const int la = pat->prow_ptr[(size_t)qa], lb = pat->prow_ptr[(size_t)qb];
       const int c1a = pat->prow_ptr[(size_t)qa + 1] - la, c1b = pat->prow_ptr[(size_t)qb + 1] - lb;  // {k+1} + U_q: >= 2 inside a run
       const int c2a = c1a - 1, c2b = c1b - 1;
       auto tile = [&](int k) { return w->S + tix(w->hco(), k, k) * NB * NB; };
       auto panel_of = [&](int k, T *V, const int *rows) { return RunPanel<T>{w->Linv + (int64_t)k * NB * NB, w->D + (int64_t)k * NB, V, k, rows}; };
+      BA_CHECK(join_rest(slot));  // (the rests of the step two back read these panel buffers)
       hipLaunchKernelGGL(k_ldl_diag2<T>, dim3(2), dim3(DIAG_THREADS), DIAG_LDS_ELEMS * sizeof(T), st, tile(ka), w->Linv + (int64_t)ka * NB * NB,
                          w->D + (int64_t)ka * NB, tile(kb), w->Linv + (int64_t)kb * NB * NB, w->D + (int64_t)kb * NB, w->flag);
       const RunPanel<T> a0 = panel_of(ka, VA, w->prow + la), b0 = panel_of(kb, VB, w->prow + lb);
@@ -2174,15 +2199,42 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
         hipLaunchKernelGGL((k_ldl_trsm_rs2<T, true>), dim3(4 * (c2a + c2b)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, a1, b1, 4 * c2a, d_b, y);
       else
         hipLaunchKernelGGL((k_ldl_trsm_rs2<T, false>), dim3(4 * (c2a + c2b)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, a1, b1, 4 * c2a, d_b, y);
-      // the two pair updates: panels (k, k+1) of either run over its U_q
-      const RunPanel<T> ua = panel_of(ka, VA, w->prow + la + 1), ub = panel_of(kb, VB, w->prow + lb + 1);
-      const int na = c2a * (c2a + 1) / 2, nb2 = c2b * (c2b + 1) / 2;
-      if (na + nb2 <= update_rs_max())
-        hipLaunchKernelGGL(k_ldl_update_rs2<T>, dim3(4 * (na + nb2)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, ua, na, ub, nb2, panel);
-      else
-        hipLaunchKernelGGL(k_ldl_update2<T>, dim3(((na + 7) / 8) * 8 + ((nb2 + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S, w->col_off,
-                           ua, na, ub, nb2, panel);
+      // the two pair updates: panels (k, k+1) of either run over its U_q -- with the look-ahead of the single run (lead strips of
+      // both runs first, both rests on a part of the chip beside the next step's chain) when the rests are long enough
+      auto nlead_of = [&](int l0, int c2, int k) {
+        int nl = 0;
+        while (nl < c2 && nl < 2 && pat->prow[(size_t)(l0 + 1 + nl)] < k + 4) nl++;
+        return nl;
+      };
+      const int nla = nlead_of(la, c2a, ka), nlb = nlead_of(lb, c2b, kb);
+      const int ra = c2a - nla, rb = c2b - nlb, rest_a = ra * (ra + 1) / 2, rest_b = rb * (rb + 1) / 2;
+      if (lookahead && i + 1 < both && rest_a + rest_b >= 2 * la_min) {
+        BA_CHECK(join_rest(slot ^ 1));
+        const int sa = nla == 0 ? 0 : (nla == 1 ? c2a : 2 * c2a - 1), sb = nlb == 0 ? 0 : (nlb == 1 ? c2b : 2 * c2b - 1);
+        const RunPanel<T> ua = panel_of(ka, VA, w->prow + la + 1), ub = panel_of(kb, VB, w->prow + lb + 1);
+        if (sa + sb > 0)
+          hipLaunchKernelGGL(k_ldl_update_rs2<T>, dim3(4 * (sa + sb)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, ua, sa, ub, sb, panel, c2a, c2b);
+        BA_HIP_CHECK(hipEventRecord(w->ev_recv[slot], st));
+        BA_HIP_CHECK(hipStreamWaitEvent(w->rest, w->ev_recv[slot], 0));
+        const RunPanel<T> qa2 = panel_of(ka, VA, w->prow + la + 1 + nla), qb2 = panel_of(kb, VB, w->prow + lb + 1 + nlb);
+        const int ntile = rest_a + rest_b;
+        hipLaunchKernelGGL(k_ldl_update_part2<T>, dim3(ntile < rest_cus ? ntile : rest_cus), dim3(256), PART_LDS_BYTES, w->rest, w->S, w->col_off,
+                           qa2, rest_a, qb2, rest_b, panel);
+        BA_HIP_CHECK(hipEventRecord(w->ev_upd[slot], w->rest));
+        pending[slot] = true;
+      } else {
+        BA_CHECK(join_rest(slot ^ 1));
+        const RunPanel<T> ua = panel_of(ka, VA, w->prow + la + 1), ub = panel_of(kb, VB, w->prow + lb + 1);
+        const int na = c2a * (c2a + 1) / 2, nb2 = c2b * (c2b + 1) / 2;
+        if (na + nb2 <= update_rs_max())
+          hipLaunchKernelGGL(k_ldl_update_rs2<T>, dim3(4 * (na + nb2)), dim3(256), RS_LDS_ELEMS * sizeof(T), st, w->S, w->col_off, ua, na, ub, nb2, panel, 0, 0);
+        else
+          hipLaunchKernelGGL(k_ldl_update2<T>, dim3(((na + 7) / 8) * 8 + ((nb2 + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S, w->col_off,
+                             ua, na, ub, nb2, panel);
+      }
     }
+    BA_CHECK(join_rest(0));
+    BA_CHECK(join_rest(1));
     BA_HIP_CHECK(hipGetLastError());
     for (int q = both; q < pat->a_clean; q++) order.push_back(q);  // the longer run's remainder, then everything else
     for (int q = pat->a_clean; q < pat->split; q++) order.push_back(q);

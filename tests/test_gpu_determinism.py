@@ -94,6 +94,16 @@ def test_block_sparse_two_chains(ba, orc, gpu_ok, shuffle):
     a1, a2, ha1, ha2, pat, perm, name = step()
     b1, _, hb1, _, _, _, _ = _env("BA_SPARSE_TWO_RUNS", "0", step)
     f1, f2, _, _, _, _, _ = step(np.float32)
+    # the look-ahead inside the two-run phase (lead strips of both runs, both rests on a part of the chip beside the next step's
+    # chain), forced on however short the rests are, against the two runs strictly in order: the same bits
+    l1, l2, _, _, _, _, _ = _env("BA_SPARSE_LOOKAHEAD_MIN", "1", step)
+    n1, _, _, _, _, _, _ = _env("BA_SPARSE_LOOKAHEAD", "0", step)
+    l32, _, _, _, _, _, _ = _env("BA_SPARSE_LOOKAHEAD_MIN", "1", lambda: step(np.float32))
+    n32, _, _, _, _, _, _ = _env("BA_SPARSE_LOOKAHEAD", "0", lambda: step(np.float32))
+    for tag, (x, y) in {"two runs with look-ahead, twice": (l1, l2), "two runs, look-ahead vs in order": (l1, n1),
+                        "two runs, look-ahead forced vs default threshold": (l1, a1), "Float32: look-ahead vs in order": (l32, n32)}.items():
+        rep = bits_report(x, y, tag)
+        assert not rep, rep
     assert name == "two-ended" and pat[2], (name, pat)
     rc, d_ref, dr_ref, _ = orc.lm_step(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"], 10.0, cam_perm1=perm)
     assert rc == 0
