@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
                                                         const int64_t *__restrict__ own_pref = nullptr, int m0 = 0,
                                                         int m_end = 0, int ready_tiles = 1, const int *__restrict__ rows = nullptr,
                                                         const T *__restrict__ Lp0 = nullptr, const T *__restrict__ Lp1 = nullptr,
-                                                        const int2 *__restrict__ tlist = nullptr) {
+                                                        const int2 *__restrict__ tlist = nullptr, int blocked = TSB) {
   // tlist (block-sparse S on several ranks): the tiles (i, j) of this launch, listed (the pattern's tiles of the pair's update
   // in the tile columns this rank owns)
   BA_VT
@@ -1349,10 +1349,20 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
       j = own_cols[lo];
       i = j + (int)(tt - own_pref[lo]);
     } else {
-      int ii = (int)((sqrt(8.0 * (T)t + 1.0) - 1.0) * 0.5);
-      while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-      while (ii * (ii + 1) / 2 > t) ii--;
-      const int jj = t - ii * (ii + 1) / 2;
+      // the lower triangle in super-blocks of 8 x 8 tiles (tri_blocked, ba_internal.h): the ~64 workgroups an XCD runs at a
+      // time share 8 + 8 row panels instead of 1 + 64 (row-major enumeration: every tile its own B panel from beyond the L2)
+      int m_rows = (int)((sqrt(8.0 * (double)nblk + 1.0) - 1.0) * 0.5);  // nblk = m_rows (m_rows + 1) / 2 tiles
+      while ((m_rows + 1) * (m_rows + 2) / 2 <= nblk) m_rows++;
+      while (m_rows * (m_rows + 1) / 2 > nblk) m_rows--;
+      int ii, jj;
+      if (blocked) {
+        tri_blocked(t, m_rows, &ii, &jj, blocked);
+      } else {
+        ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+        while (ii * (ii + 1) / 2 > t) ii--;
+        jj = t - ii * (ii + 1) / 2;
+      }
       // rows (block-sparse S): the pair's pattern, ascending -- tile (rows[ii], rows[jj]) instead of (base + ii, base + jj)
       i = rows ? rows[ii] : base + ii;
       j = rows ? rows[jj] : base + jj;
@@ -1830,9 +1840,10 @@ static int launch_pair(ba_problem *p, DenseLDLT<T> *w, int k, int base, const T 
   // (Cutting the tiles of a partly filled last round into 64 x 64 quadrants, one workgroup each, was tried and removed:
   // 34.1-34.3 ms against 33.9-34.1 at n = 16 002.  A partial round does not cost a full one -- the quadrant kernel took
   // 39 us on average, which is what the big kernel's own last round costs.)
+  static const int blocked = [] { const char *e = getenv("BA_LDL_TRI_BLOCKED"); return e ? atoi(e) : TSB; }();
   hipLaunchKernelGGL((k_ldl_update<T, 1>), dim3(((nblk + 7) / 8) * 8), dim3(256), gemm_priv_lds_bytes<T>(), st, w->S,
                      w->col_off, V0, V1, k, base, nt, nblk, ready, (const int *)nullptr, (const int64_t *)nullptr, 0, 0,
-                     ready_tiles);
+                     ready_tiles, (const int *)nullptr, (const T *)nullptr, (const T *)nullptr, (const int2 *)nullptr, blocked);
   return BA_OK;
 }
 

@@ -36,6 +36,37 @@ constexpr int NB = 128;
 // head of its table: col_off[-1] = 0 for the dense layout (a tile column is contiguous: col_off[j] + (i - j)), or = nt for the
 // compressed layout of a block-sparse pattern, where col_off[nt + i nt + j] is the position of tile row i among the stored
 // rows of column j (negative, and so a negative result, for a tile outside the pattern: nothing is allocated for it).
+// Enumeration of the lower triangle of an m x m tile grid in SUPER-BLOCKS of TSB x TSB tiles (block rows top to bottom, blocks
+// left to right, row-major inside a block; the diagonal blocks hold their lower triangle): t -> (ii, jj), jj <= ii.  The
+// workgroups of the bulk trailing update that run at the same time (consecutive t) then share TSB row panels of each
+// operand instead of one panel of A and one panel PER TILE of B -- the operand reads that miss the XCD's L2 drop by ~TSB / 2.
+// t = 0, 1, 2 are (0,0), (1,0), (1,1): what the hoisted diagonal kernels wait for.
+constexpr int TSB = 8;
+__host__ __device__ inline void tri_blocked(int t, int m, int *ii, int *jj, int sb = TSB) {
+  // tiles before block row bi (all block rows above it are full): sum_{r < bi} (sb^2 r + sb (sb + 1) / 2)
+  const int full = sb * sb, tri = sb * (sb + 1) / 2;
+  int lo = 0, hi = (m + sb - 1) / sb;  // largest bi with start(bi) <= t
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (full * mid * (mid - 1) / 2 + tri * mid <= t) lo = mid;
+    else hi = mid;
+  }
+  const int bi = lo;
+  int rem = t - (full * bi * (bi - 1) / 2 + tri * bi);
+  const int h = (m - sb * bi) < sb ? (m - sb * bi) : sb;  // tile rows in this block row
+  if (rem < bi * sb * h) {
+    const int bj = rem / (sb * h), r2 = rem - bj * (sb * h);
+    *ii = sb * bi + r2 / sb;
+    *jj = sb * bj + r2 % sb;
+  } else {
+    rem -= bi * sb * h;
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= rem) r++;
+    *ii = sb * bi + r;
+    *jj = sb * bi + rem - r * (r + 1) / 2;
+  }
+}
+
 __host__ __device__ inline int64_t tix(const int64_t *__restrict__ col_off, int64_t i, int64_t j) {
   const int64_t n = col_off[-1];
   return col_off[j] + (n ? col_off[n + i * n + j] : (i - j));

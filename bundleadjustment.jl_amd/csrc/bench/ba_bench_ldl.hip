@@ -8,7 +8,8 @@
 // DBG: bit 0 = store instead of read-modify-write, bit 1 = every workgroup reads the same operand tiles (L2-resident
 // operands), bit 3 = workgroup-shared LDS staging with barriers (the first version: 52.6 TFLOP/s against 59.8 for the
 // wave-private staging that ships), bit 4 = LDS-DMA staging, bit 5 = K = 512 (four panels per pass), bit 6 = accumulators
-// started from -C.  DBG = 0 is the product kernel k_ldl_update itself.
+// started from -C, bit 7 = direct operand loads without LDS (bits 8-12: its sub-probes), bit 13 = super-block enumeration of the
+// triangle (adopted in the product kernel).  DBG = 0 is the product kernel k_ldl_update itself.
 namespace {
 // LDS-DMA variant of the wave-private product (Float64): the operand chunks go global -> LDS directly
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write, no wait between a load and its LDS write), chunks of 8, two LDS
@@ -17,6 +18,79 @@ namespace {
 // XOR-swizzled with the row ((row >> 2) & 3), which keeps the MFMA operand reads at two dwords per bank.  Same products in
 // the same order as tile_gemm_abt_priv (bit-identical accumulators; tools/bench_mfma_probe.py modes 3 / 5 compare their
 // checksums).  Probe, nonzero operands, steady state: 68.6-68.7 TFLOP/s against 66.1-66.2 for the register-staged loop.
+// Direct-operand variant of the wave-private product (probe; bits 7-12 of DBG): NO LDS.  The A / B operand of the 16x16x4 matrix instruction is "lane l holds element
+// [row l & 15][k = l >> 4]" of a K-contiguous row -- exactly what a lane reads from a row-major tile, so the wave-private
+// staging above passes every operand byte through LDS (a 16-byte write and an 8-byte read per element pair) without
+// sharing or transposing anything.  Here a lane loads 16 bytes of ITS row straight into registers: VL = 2 doubles (4 floats)
+// that feed VL consecutive matrix instructions.  A group = 4 VL consecutive k (64 bytes of every row: the 4 lanes of a row
+// cover it); lane (fr, fk) holds k = g 4 VL + VL fk + s for step s of group g.  Within a step the four fk lanes thus carry
+// k = 4VL g + s, + VL, + 2VL, + 3VL instead of four consecutive k: a permutation of the K sum (same products, another
+// order: adopting it would need the same permutation -- kperm -- in the row-split update, whose bits must equal this kernel's).
+// Three register slots of 8 loads each: group g is multiplied while g + 1 and g + 2 are in flight.
+// Measured (profiles/r04_f_update_probes.txt): the same speed as the LDS-staged product kernel (58.7 against 60.0 TFLOP/s on
+// zero operands, 57.7 against 56.6 on full-entropy ones) -- the staging is not what the kernel waits for.  PROBE bits:
+// 1 half the loads (+11 %), 2 L1-resident operands (+11 %), 4 / 8 / 16 workgroup barriers that keep the waves in step (0 %).
+template <typename T>
+__device__ __forceinline__ int kperm(int s4, int fk) {  // the k (within a panel) of matrix-instruction step s4, lane group fk
+  constexpr int VL = 16 / sizeof(T);
+  return (s4 / VL) * 4 * VL + VL * fk + (s4 % VL);
+}
+template <typename T, int NP, int PROBE = 0>
+__device__ inline void tile_gemm_abt_direct(const T *__restrict__ A0, const T *__restrict__ B0,
+                                            const T *__restrict__ A1, const T *__restrict__ B1,
+                                            typename RT<T>::v4 acc[4][4], const T *__restrict__ A2 = nullptr,
+                                            const T *__restrict__ B2 = nullptr, const T *__restrict__ A3 = nullptr,
+                                            const T *__restrict__ B3 = nullptr) {
+  typedef typename PV<T>::vu vu;
+  constexpr int VL = PV<T>::VL, GK = 4 * VL, GPP = NB / GK, NG = NP * GPP, R = 3;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  const int fr = lane & 15, fk = lane >> 4;
+  uint32_t voff[4];  // the lane's byte offset inside the 64-row slice, per 16-row block (uniform bases: one VGPR each)
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    voff[m] = (uint32_t)(((16 * m + fr) * NB + VL * fk) * sizeof(T));
+    asm volatile("" : "+v"(voff[m]));
+  }
+  vu ra[R][4], rb[R][4];
+  // the tile addresses are the same for every lane of the workgroup, but come out of per-lane arithmetic (the triangular
+  // index): told so, the compiler keeps them in scalar registers and every load is base (scalar) + lane offset + immediate
+  auto uni = [](const T *q) {
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    return reinterpret_cast<const T *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
+  };
+  typedef __attribute__((address_space(1))) char gchar;  // (global address space: the rebuilt pointers would be generic)
+  typedef __attribute__((address_space(1))) vu gvu;
+  const T *Ap[4] = {uni(A0), uni(A1), NP > 2 ? uni(A2) : nullptr, NP > 2 ? uni(A3) : nullptr};
+  const T *Bp[4] = {uni(B0), uni(B1), NP > 2 ? uni(B2) : nullptr, NP > 2 ? uni(B3) : nullptr};
+  auto issue = [&](int g, int slot) {
+    const int pn = g / GPP, kq = (PROBE & 2) ? 0 : g % GPP;  // (probe 2: every group re-reads group 0 -- L1-resident operands)
+    const gchar *a = (const gchar *)(Ap[pn] + wr * NB + kq * GK);
+    const gchar *b = (const gchar *)(Bp[pn] + wc * NB + kq * GK);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      ra[slot][m] = *(const gvu *)(a + voff[m]);
+      if (!(PROBE & 1)) rb[slot][m] = *(const gvu *)(b + voff[m]);  // (probe 1: half the loads, B := A)
+      else rb[slot][m] = ra[slot][m];
+    }
+  };
+  issue(0, 0);
+  issue(1, 1);
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    if ((PROBE & 4) || ((PROBE & 8) && (g & 3) == 0) || ((PROBE & 16) && (g & 1) == 0)) __builtin_amdgcn_s_barrier();  // (probe: keep the four waves in step so that the slices two of them share hit in L1)
+    if (g + 2 < NG) issue(g + 2, (g + 2) % R);
+#pragma unroll
+    for (int s = 0; s < VL; s++)
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = RT<T>::mfma(ra[g % R][m][s], rb[g % R][n][s], acc[m][n]);
+  }
+}
+
 constexpr int DKC = 8;
 constexpr size_t GEMM_DMA_LDS_ELEMS = (size_t)4 * 2 * 2 * 64 * DKC;
 __device__ inline void tile_gemm_abt_dma(const double *__restrict__ A0, const double *__restrict__ B0,
@@ -108,7 +182,8 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update_probe(T *__restrict__ S, 
       int ii = (int)((sqrt(8.0 * (T)t + 1.0) - 1.0) * 0.5);
       while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
       while (ii * (ii + 1) / 2 > t) ii--;
-      const int jj = t - ii * (ii + 1) / 2;
+      int jj = t - ii * (ii + 1) / 2;
+      if constexpr ((DBG & 8192) != 0) tri_blocked(t, nt - base, &ii, &jj);  // super-block enumeration (L2 reuse of both operands)
       // rows (block-sparse S): the pair's pattern, ascending -- tile (rows[ii], rows[jj]) instead of (base + ii, base + jj)
       i = rows ? rows[ii] : base + ii;
       j = rows ? rows[jj] : base + jj;
@@ -140,6 +215,9 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update_probe(T *__restrict__ S, 
     tile_gemm_abt_priv<T, 4>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
                           S + tix(co, jo, k + 1) * NB * NB, lds, acc, V1 + (int64_t)(nt + io) * NB * NB,
                           S + tix(co, jo, k + 2) * NB * NB, V1 + (int64_t)(2 * nt + io) * NB * NB, S + tix(co, jo, k + 3) * NB * NB);
+  else if constexpr ((DBG & 128) != 0)  // direct operand loads, no LDS (bits 8 / 9: half the loads / L1-resident operands)
+    tile_gemm_abt_direct<T, 2, ((DBG & 256) ? 1 : 0) | ((DBG & 512) ? 2 : 0) | ((DBG & 1024) ? 4 : 0) | ((DBG & 2048) ? 8 : 0) | ((DBG & 4096) ? 16 : 0)>(V0 + (int64_t)io * NB * NB, S + tix(co, jo, k) * NB * NB, V1 + (int64_t)io * NB * NB,
+                               S + tix(co, jo, k + 1) * NB * NB, acc);
   else if (!(DBG & 8))
     // Lp0 / Lp1 (distributed factorisation with per-rank ownership of S): the L tiles of the two panels come from the panel
     // buffers the broadcast filled (tile row j at Lp + j NB^2) -- a rank holds only its own tile columns of S
@@ -217,6 +295,12 @@ static int set_bench_kernel_attrs() {
   BA_CHECK(set_kernel_attrs<T>());
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 8192>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 8193>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
+  BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 3>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 2>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_PRIV_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_probe<T, 1, 8>),
@@ -274,6 +358,24 @@ extern "C" int ba_debug_update_bench(int nt, int variant, int reps, double *ms_o
       case 32: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 32>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
       case 33: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 33>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 4, nt, nblk, (int *)nullptr); break;
       case 64: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 64>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 128: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 128>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 385: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 385>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 641: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 641>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 897: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 897>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 1152: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 1152>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 1153: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 1153>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 2176: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 2176>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 2177: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 2177>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 4224: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 4224>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 4225: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 4225>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 130: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 130>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 131: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 131>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 3: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 3>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 8192: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 8192>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 8193: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 8193>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 8320: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 8320>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 8321: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 8321>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
+      case 129: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 129>), dim3(grid), dim3(256), 0, 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       case 9: hipLaunchKernelGGL((k_ldl_update_probe<double, 1, 9>), dim3(grid), dim3(256), GEMM_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr); break;
       default: hipLaunchKernelGGL((k_ldl_update<double, 1>), dim3(grid), dim3(256), GEMM_PRIV_LDS_ELEMS * sizeof(double), 0, S, co, V0, V1, 0, 2, nt, nblk, (int *)nullptr);
     }

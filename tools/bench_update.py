@@ -1,6 +1,9 @@
 """Micro-benchmark of the bulk trailing update kernel (K = 256 pair update) on an nt x nt tile matrix.
 variants: 0 real (wave-private LDS staging), 1 store-only epilogue, 2 L2-resident operands, 8 workgroup-shared staging
-with barriers (first version), 9 = 8 + store-only."""
+with barriers (first version), 9 = 8 + store-only, 16 LDS-DMA staging, 32 K = 512, 64 accumulators started from -C,
+128 direct operand loads without LDS (+256 half the loads, +512 L1-resident operands, +1024 / +2048 / +4096 a workgroup
+barrier every 1 / 4 / 2 K groups), 8192 super-block enumeration of the triangle; +1 on any of them: store-only epilogue.
+BA_BENCH_NONZERO=1 BA_BENCH_ENTROPY=1: full-entropy mantissas (what a real matrix holds; the chip clocks lower on them)."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _benchlib
