@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--locality", type=float, default=None,
                     help="cameras of a point drawn from a window of this fraction of the cameras: block-banded reduced camera "
                          "matrix (synthetic.make_problem); default: every camera pair shares points, dense S")
+    ap.add_argument("--plane-radius", type=float, default=None,
+                    help="cameras standing in the plane, a point seen from one neighbourhood of this radius (unit square): a sparse "
+                         "reduced camera matrix with NO band in the numbering it comes with (synthetic._cameras_in_the_plane)")
     ap.add_argument("--shuffle-cameras", action="store_true",
                     help="renumber the cameras at random (synthetic.shuffle_cameras): what `perm` has to undo (not the headline configuration)")
     ap.add_argument("--perm", choices=["AMD", "Metis", "natural"], default="AMD",
@@ -174,7 +177,7 @@ def main():
 
     # ---- workload ---------------------------------------------------------------------------------------------------
     t0 = time.time()
-    prob = ba.synthetic.make_named(args.workload, scale=args.scale, locality=args.locality)
+    prob = ba.synthetic.make_named(args.workload, scale=args.scale, locality=args.locality, plane_radius=args.plane_radius)
     if args.shuffle_cameras:
         prob, _ = ba.synthetic.shuffle_cameras(prob, seed=ba.synthetic.BASE_SEED)
     arrays = ba.synthetic.as_arrays(prob)
@@ -420,6 +423,7 @@ def main():
                                    f"{ba.synthetic.BASE_SEED}, lm.jl variant, {FACTO}/None" + (f" (pcg_tol {PCG_TOL:g})" if FACTO == "PCG" else "") + f", facto_type {args.facto_type}, fixed {args.steps} iterations"
                                    + ("" if args.scale == 1.0 else f" SCALED x{args.scale} (debug)")
                                    + ("" if args.locality is None else f" LOCALITY {args.locality} (block-banded S; not the headline configuration)")
+                                   + ("" if args.plane_radius is None else f" CAMERAS IN THE PLANE, radius {args.plane_radius} (geometric camera graph, numbering without structure; not the headline configuration)")
                                    + (" CAMERAS RENUMBERED AT RANDOM" if args.shuffle_cameras else "") + f", perm {PERM}"
                                    + (f" EMULATED SHARD {args.emulate_shard} (one rank's compute, no communicator)" if args.emulate_shard else ""),
                        "parallelism": f"points sharded over {world} rank(s), cameras replicated"

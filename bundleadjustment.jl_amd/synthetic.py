@@ -60,8 +60,36 @@ def _degrees(rng, npnts, nobs, ncams):
     return deg
 
 
-def make_problem(ncams, npnts, nobs, seed=BASE_SEED, locality=None):
+def _cameras_in_the_plane(rng, ncams, npnts, nobs, radius):
+    """Observation graph of a scene laid out in the plane (street-level captures of a town): every camera has a random position
+    in the unit square -- unrelated to its NUMBER -- and a point is seen by cameras among the K = ncams * pi * radius^2 nearest
+    to a random centre.  Two cameras share points when they stand within ~2 radius of each other: the camera graph is a
+    two-dimensional geometric graph whose numbering carries no structure.  -> (pnt0, cam0) sorted by point then camera."""
+    from scipy.spatial import cKDTree
+    pos = rng.random((ncams, 2))
+    K = int(min(ncams, max(2, round(ncams * np.pi * radius * radius))))
+    deg = _degrees(rng, npnts, nobs, K)
+    tree = cKDTree(pos)
+    cam0 = np.empty(nobs, dtype=np.int64)
+    start = np.concatenate([[0], np.cumsum(deg)])
+    for lo in range(0, npnts, 200000):  # chunks: the candidate table is (points, K)
+        hi = min(npnts, lo + 200000)
+        _, near = tree.query(rng.random((hi - lo, 2)), k=K)
+        near = near.reshape(hi - lo, K)
+        pick = np.argsort(rng.random((hi - lo, K)), axis=1)  # a random subset of the candidates: the first deg of a shuffle
+        d = deg[lo:hi]
+        mask = np.arange(K)[None, :] < d[:, None]
+        cam0[start[lo]:start[hi]] = np.take_along_axis(near, pick, axis=1)[mask]
+    pnt0 = np.repeat(np.arange(npnts, dtype=np.int64), deg)
+    order = np.lexsort((cam0, pnt0))
+    return pnt0, cam0[order]
+
+
+def make_problem(ncams, npnts, nobs, seed=BASE_SEED, locality=None, plane_radius=None):
     """-> dict(cam_idx1, pnt_idx1, pt2d, x0, x_true, ncams, npnts, nobs) in the reference's conventions.
+
+    plane_radius (None or a radius in the unit square): the cameras stand in the plane and a point is seen from one
+    neighbourhood (_cameras_in_the_plane): a sparse reduced camera matrix WITHOUT a band in the numbering it comes with.
 
     locality (None or a fraction in (0, 1]): None draws the cameras of a point uniformly from ALL cameras -- every camera
     pair then shares points and the reduced camera matrix S is dense (its block fill is 1).  With locality = w a point is
@@ -87,7 +115,12 @@ def make_problem(ncams, npnts, nobs, seed=BASE_SEED, locality=None):
     k2 = rng.uniform(0.0, 1.0, size=ncams) * 1e-12
     cams = np.column_stack([rvec, tvec, k1, k2, f])
     # observation graph
-    if locality is None:
+    if plane_radius is not None:
+        if locality is not None:
+            raise ValueError("locality and plane_radius are two different observation graphs")
+        pnt0, cam0 = _cameras_in_the_plane(rng, ncams, npnts, nobs, float(plane_radius))
+        lo_cam, width = None, 0
+    elif locality is None:
         deg = _degrees(rng, npnts, nobs, ncams)
         pnt0 = np.repeat(np.arange(npnts, dtype=np.int64), deg)
         lo_cam = np.zeros(nobs, dtype=np.int64)
@@ -97,8 +130,9 @@ def make_problem(ncams, npnts, nobs, seed=BASE_SEED, locality=None):
         deg = _degrees(rng, npnts, nobs, width)
         pnt0 = np.repeat(np.arange(npnts, dtype=np.int64), deg)
         lo_cam = np.repeat(rng.integers(0, ncams - width + 1, size=npnts, dtype=np.int64), deg)  # window start of the point
-    cam0 = lo_cam + rng.integers(0, width, size=nobs, dtype=np.int64)
-    for _ in range(400):
+    if lo_cam is not None:
+        cam0 = lo_cam + rng.integers(0, width, size=nobs, dtype=np.int64)
+    for _ in range(400 if lo_cam is not None else 0):
         order = np.lexsort((cam0, pnt0))
         cam0, lo_cam = cam0[order], lo_cam[order]
         dup = np.flatnonzero((pnt0[1:] == pnt0[:-1]) & (cam0[1:] == cam0[:-1])) + 1
@@ -106,7 +140,8 @@ def make_problem(ncams, npnts, nobs, seed=BASE_SEED, locality=None):
             break
         cam0[dup] = lo_cam[dup] + rng.integers(0, width, size=dup.size, dtype=np.int64)
     else:
-        raise RuntimeError("could not draw distinct cameras per point")
+        if lo_cam is not None:
+            raise RuntimeError("could not draw distinct cameras per point")
     proj = project(pts[pnt0], cams[cam0])
     pt2d = (proj + rng.normal(0.0, 0.5, size=proj.shape)).ravel()
     x_true = np.concatenate([pts.ravel(), cams.ravel()])
@@ -184,7 +219,7 @@ def schur_fill(prob, tile=128):
     return block_fill, tile_fill
 
 
-def make_named(name, seed_offset=0, scale=1.0, locality=None):
+def make_named(name, seed_offset=0, scale=1.0, locality=None, plane_radius=None):
     """One of SHAPES, optionally shrunk by `scale` (observations per point kept)."""
     ncams, npnts, nobs = SHAPES[name]
     if scale != 1.0:
@@ -193,7 +228,7 @@ def make_named(name, seed_offset=0, scale=1.0, locality=None):
         nobs = max(2 * npnts2, int(round(nobs * npnts2 / npnts)))
         nobs = min(nobs, ncams * npnts2)
         npnts = npnts2
-    return make_problem(ncams, npnts, nobs, BASE_SEED + seed_offset, locality=locality)
+    return make_problem(ncams, npnts, nobs, BASE_SEED + seed_offset, locality=locality, plane_radius=plane_radius)
 
 
 def as_arrays(prob, T=np.float64):

@@ -1219,6 +1219,48 @@ def test_camera_ordering_on_a_randomly_numbered_problem(ba, orc, gpu_ok, method)
     assert np.max(np.abs(jtr1 - jtr_ref)) <= 1e-10 * np.max(np.abs(jtr_ref))  # J'r stays in the caller's numbering
 
 
+@pytest.mark.parametrize("facto_f32", [False, True])
+def test_camera_ordering_of_a_scene_in_the_plane(ba, orc, gpu_ok, facto_f32):
+    """Cameras standing in the plane, numbered without any structure (synthetic.make_problem(plane_radius=...)): the camera
+    graph is a two-dimensional geometric graph, not a band in ANY numbering -- the ordered pattern has row lists with gaps, a
+    wide frontier.  With `perm` the list schedule is chosen by itself, the step equals the
+    oracle's (ldl_analyse handed the same camera sequence) and the unordered dense-schedule step; a complete lm.jl run follows
+    the oracle's.  facto_f32: the same pattern through the Float32 factorisation (Float32 level)."""
+    p = ba.synthetic.make_problem(480, 4000, 20000, seed=43, plane_radius=0.12)  # n = 4320: 34 tile rows
+    lam = 2.0
+
+    def run(order):
+        m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+        ba.set_ordering(m, order)
+        d, half, jtr = ba.lm_step(m, p["x0"], lam, facto_type=np.float32 if facto_f32 else None)
+        pat, used = ba.schur_pattern(m), ba.schur_ordering_used(m)
+        m.close()
+        return d, pat, used
+
+    dn, patn, _ = run("natural")
+    d1, pat1, (perm1, name1) = run("AMD")
+    print(f"plane: tile fill {patn[0]:.3f} as numbered -> {pat1[0]:.3f} ('{name1}'), update tiles / dense {pat1[1]:.4f}, list schedule {pat1[2]}")
+    assert patn[0] > 0.95 and not patn[2] and pat1[0] < 0.6 and pat1[2]
+    rc, d_ref, _, _ = orc.lm_step(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"], lam, cam_perm1=perm1)
+    assert rc == 0
+    e_orc = np.linalg.norm(d1 - d_ref) / np.linalg.norm(d_ref)
+    e_dense = np.linalg.norm(d1 - dn) / np.linalg.norm(dn)
+    _report("camera_ordering_plane_" + ("f32" if facto_f32 else "f64"), step_vs_oracle=e_orc, step_vs_dense_schedule=e_dense,
+            tile_fill=pat1[0], sequence=name1)
+    tol_o, tol_d = (5e-4, 5e-4) if facto_f32 else (1e-9, 1e-10)  # measured 3.7e-5 / 7.9e-6 and 4.6e-12 / 4.0e-14 (800 cameras)
+    assert e_orc <= tol_o, f"ordered step vs oracle: {e_orc:.3e}"
+    assert e_dense <= tol_d, f"ordered (list schedule) vs unordered (dense schedule): {e_dense:.3e}"
+    if not facto_f32:
+        rc, x_ref, st_ref, log_ref = orc.lm_solve(p["ncams"], p["npnts"], p["cam_idx1"], p["pnt_idx1"], p["pt2d"], p["x0"], variant=1, ite_max=3)
+        assert rc == 0
+        m = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(p))
+        st = ba.Levenberg_Marquardt(ba.FeasibilityResidual(m), "LDL", "Metis", "None", False, ite_max=3)
+        m.close()
+        assert st.iter == st_ref.iter and st.status == orc.STATUS[st_ref.status]
+        _compare_rows(st, log_ref, _well_conditioned_prefix(log_ref))
+        assert abs(st.objective - st_ref.objective) <= 1e-8 * st_ref.objective
+
+
 def test_camera_ordering_through_levenberg_marquardt(ba, orc, gpu_ok):
     """`perm` reaches the device through Levenberg_Marquardt (ba_lm_opts.perm): complete lm.jl runs on a randomly numbered
     problem with :AMD, :Metis and with the caller's numbering agree with the oracle's run (iterations, status, rows), with

@@ -92,3 +92,23 @@ def test_two_ended_elimination_of_a_long_profile(ba):
         perm, tf, ff, _ = ba.schur_ordering(prob["cam_idx1"], prob["pnt_idx1"], prob["ncams"], prob["npnts"], "AMD")
         assert sorted(perm.tolist()) == list(range(1, 1101))
         assert tf <= 1.25 * tf_nat, (tf, tf_nat)
+
+
+def test_cameras_in_the_plane(ba):
+    """A scene laid out in the plane (synthetic.make_problem(plane_radius=...)): the camera graph is a two-dimensional
+    geometric graph and the cameras' numbers carry no structure at all -- as numbered, every tile of S is occupied.  Either
+    method must bring the tile pattern down to a fraction (the sequences compete at tile granularity: DESIGN 5c)."""
+    p = ba.synthetic.make_problem(900, 9000, 45000, seed=41, plane_radius=0.09)
+    cam, pnt = p["cam_idx1"], p["pnt_idx1"]
+    same = pnt[1:] == pnt[:-1]
+    assert np.all(np.diff(pnt) >= 0) and np.all(cam[1:][same] > cam[:-1][same])  # BAL order, a camera once per point
+    assert np.bincount(pnt - 1, minlength=p["npnts"]).min() >= 2
+    _, tf_nat, ff_nat, bf = ba.schur_ordering(cam, pnt, p["ncams"], p["npnts"], "natural")
+    assert tf_nat > 0.95 and bf < 0.15
+    for method in ("AMD", "Metis"):
+        perm, tf, ff, _ = ba.schur_ordering(cam, pnt, p["ncams"], p["npnts"], method)
+        print(f"{method}: tile fill {tf:.3f} (as numbered {tf_nat:.3f}), update flops {ff:.3f} of the dense factorisation's; block fill {bf:.3f}")
+        assert sorted(perm.tolist()) == list(range(1, p["ncams"] + 1))
+        assert tf < 0.5 and ff < 0.2
+        perm2, _, _, _ = ba.schur_ordering(cam, pnt, p["ncams"], p["npnts"], method)
+        assert np.array_equal(perm, perm2)
