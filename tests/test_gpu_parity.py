@@ -189,7 +189,10 @@ def test_dense_ldl_vs_numpy(ba, n, gpu_ok):
     b = rng.standard_normal(n)
     x, ms = ba._lib.dense_ldl_solve(A, b)
     x_ref = np.linalg.solve(A, b)
-    assert np.linalg.norm(x - x_ref) <= 1e-10 * np.linalg.norm(x_ref) * np.linalg.cond(A) ** 0.5
+    # cond(A): eigenvalues of G G' + I / 2 lie in [0.5, (sqrt(n) + sqrt(n + 8))^2 + 0.5] -- about 8 n; the large cases take the
+    # bound (the SVD of an 8100 x 8100 matrix is 100 s of host time)
+    cond = np.linalg.cond(A) if n < 2000 else 8.0 * n + 70.0
+    assert np.linalg.norm(x - x_ref) <= 1e-10 * np.linalg.norm(x_ref) * cond ** 0.5
 
 
 @pytest.mark.parametrize("n", [64, 300, 1000])
