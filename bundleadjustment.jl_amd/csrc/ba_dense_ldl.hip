@@ -796,7 +796,7 @@ __device__ inline void tile_gemm_rows(const T *__restrict__ A, const T *__restri
 // rows [32 rq, 32 rq + 32) of X_i = S_ik Linv_k' -> V_i, S_ik = X_i D_k^-1; FWD: y_k and b_i -= L_ik y_k ride along.
 // grid = 4 (nt-k-1): i = k + 1 + blockIdx.x / 4, rq = blockIdx.x % 4
 template <typename T, bool FWD>
-__device__ inline void ldl_trsm_rs_body(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv_k,
+__device__ __forceinline__ void ldl_trsm_rs_body(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv_k,
                                         const T *__restrict__ D_k, T *__restrict__ V, int k, T *__restrict__ b, T *__restrict__ y,
                                         const int *__restrict__ rows, const int bid) {
   BA_VT
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void k_ldl_trsm_rs2(T *__restrict__ S, const i
 
 // rows [32 rq, 32 rq + 32) of S_{i,k+1} -= V0_i L_{k+1,k}'   (grid = 4 (nt-k-1))
 template <typename T>
-__device__ inline void ldl_col_rs_body(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, int k,
+__device__ __forceinline__ void ldl_col_rs_body(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, int k,
                                        const int *__restrict__ rows, const int bid) {
   BA_VT
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(256) void k_ldl_col_rs2(T *__restrict__ S, const in
 // updated -- (rows[ii], rows[0]), ii = 0 .. lead_len-1, then (rows[ii], rows[1]), ii = 1 .. lead_len-1 -- what the next pair's
 // panel chain needs; the rest of the update runs beside that chain (dense_ldl_factor_sparse).
 template <typename T>
-__device__ inline void ldl_update_rs_body(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
+__device__ __forceinline__ void ldl_update_rs_body(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
                                           const T *__restrict__ V1, int k, int base, int nblk, const int *__restrict__ rows,
                                           int lead_len, const int bid) {
   BA_VT
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_ldl_pairdiag(T *__restrict__ S, const i
 
 // one tile of the pair update: S_ij -= V0_i L_jk' + V1_i L_{j,k+1}' (K = 256) by the four waves of a workgroup
 template <typename T>
-__device__ inline void ldl_update_tile(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, const T *__restrict__ V1,
+__device__ __forceinline__ void ldl_update_tile(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0, const T *__restrict__ V1,
                                        int k, int i, int j, T *lds, const T *__restrict__ Lp0, const T *__restrict__ Lp1) {
   BA_VT
   T *Sij = S + tix(co, i, j) * NB * NB;
@@ -1541,9 +1541,9 @@ __global__ __launch_bounds__(256) void k_bwd_step(const T *__restrict__ S, const
 // launch halve it).  Every workgroup recomputes x_k, the correction of y_{k-1} and x_{k-1} (three 128 x 128 products on
 // L2-resident tiles); block 0 stores them, block j+1 applies both panels to y_j, j < k-1.
 template <typename T>
-__global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
-                                                   const T *__restrict__ D, T *__restrict__ y, T *__restrict__ x, int k,
-                                                   const int *__restrict__ cols = nullptr) {
+__device__ __forceinline__ void bwd_pair_body(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
+                                     const T *__restrict__ D, T *__restrict__ y, T *__restrict__ x, int k,
+                                     const int *__restrict__ cols, const int bid) {
   __shared__ T zk[NB], xk[NB], xk1[NB], part[2][NB];
   const int tid = threadIdx.x;
   const int c = tid & (NB - 1), half = tid >> 7;
@@ -1555,7 +1555,7 @@ __global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const
   // the tile indices first (compressed block-sparse storage: a tile outside the pattern does not exist): their table
   // look-ups are dependent global loads, which left where they are used put three memory round trips on the chain of a
   // launch that has nothing to hide them behind (19 -> 32 us per launch on Venice when the tables came in)
-  const int j = blockIdx.x == 0 ? 0 : (cols ? cols[blockIdx.x - 1] : blockIdx.x - 1);  // 0 .. k-2
+  const int j = bid == 0 ? 0 : (cols ? cols[bid - 1] : bid - 1);  // 0 .. k-2
   const int64_t tkk = tix(co, k, k - 1), tkj = tix(co, k, j), tk1j = tix(co, k - 1, j);
   if (tid < NB) zk[tid] = y[(int64_t)k * NB + tid] / D[(int64_t)k * NB + tid];
   __syncthreads();
@@ -1575,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const
   __syncthreads();
   if (tid < NB) xk1[tid] = part[0][tid] + part[1][tid];
   __syncthreads();
-  if (blockIdx.x == 0) {
+  if (bid == 0) {
     if (tid < NB) {
       x[(int64_t)k * NB + tid] = xk[tid];
       x[(int64_t)(k - 1) * NB + tid] = xk1[tid];
@@ -1596,6 +1596,24 @@ __global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const
   __syncthreads();
   if (tid < NB) y[(int64_t)j * NB + tid] -= D[(int64_t)j * NB + tid] * (part[0][tid] + part[1][tid]);
 }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bwd_pair(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
+                                                   const T *__restrict__ D, T *__restrict__ y, T *__restrict__ x, int k,
+                                                   const int *__restrict__ cols = nullptr) {
+  bwd_pair_body<T>(S, co, Linv, D, y, x, k, cols, (int)blockIdx.x);
+}
+// The row pairs of TWO independent groups of tile columns in one launch (block-sparse S eliminated from both ends,
+// dense_ldl_solve): rows (ka, ka-1) by the first na workgroups, rows (kc, kc-1) by the others.  The two groups' rows have no
+// pattern column in common, so the two halves update disjoint parts of y.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bwd_pair2(const T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ Linv,
+                                                    const T *__restrict__ D, T *__restrict__ y, T *__restrict__ x, int ka,
+                                                    const int *__restrict__ cols_a, int na, int kc, const int *__restrict__ cols_c) {
+  const bool second = (int)blockIdx.x >= na;
+  bwd_pair_body<T>(S, co, Linv, D, y, x, second ? kc : ka, second ? cols_c : cols_a, (int)blockIdx.x - (second ? na : 0));
+}
+
 
 }  // namespace
 
@@ -2687,14 +2705,41 @@ int dense_ldl_solve(ba_problem *p, DenseLDLT<T> *w, T *d_b, hipStream_t st, bool
       ba_set_error("block-sparse reduced camera system: the forward substitution rides along with the factorisation");
       return BA_ERR_ARG;
     }
-    int k = nt - 1;
-    for (int q = 0; k >= 1; k -= 2, q++) {  // tile rows k, k-1 per launch over the union of their pattern columns
-      const int c0 = pat->lpair_ptr[(size_t)q], c1 = pat->lpair_ptr[(size_t)q + 1];
-      hipLaunchKernelGGL(k_bwd_pair<T>, dim3(1 + (c1 - c0)), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, k, w->lpair + c0);
-    }
-    for (; k >= 0; k--) {
-      const int c0 = pat->lcol_ptr[(size_t)k], c1 = pat->lcol_ptr[(size_t)k + 1];
-      hipLaunchKernelGGL(k_bwd_step<T>, dim3(1 + (c1 - c0)), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, k, w->lcol + c0);
+    // The tile rows of one tile column pair (2q + 1, 2q) per launch over the union of their pattern columns (a last single row
+    // when nt is odd), last pair first.  Two groups of columns (TilePattern::split / b_clean: the ordering eliminated a
+    // profile from both ends): the rows [2 split, 2 (split + b_clean)) have no pattern column before the split -- no pair of the
+    // first group touches them -- and the rows before the split none behind it, so once the rows behind both groups are done
+    // the two groups' sweeps are independent: two pairs per launch (k_bwd_pair2).  Every y_j receives its updates in the same
+    // sequence as in the one-pair-per-launch sweep: same bits.
+    const int npairs = (nt + 1) / 2;
+    auto single = [&](int q) {
+      const int k = 2 * q + 1;
+      if (k >= nt) {
+        const int c0 = pat->lcol_ptr[(size_t)(nt - 1)], c1 = pat->lcol_ptr[(size_t)nt];
+        hipLaunchKernelGGL(k_bwd_step<T>, dim3(1 + (c1 - c0)), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, nt - 1, w->lcol + c0);
+      } else {
+        const int c0 = pat->lpair_ptr[(size_t)q], c1 = pat->lpair_ptr[(size_t)q + 1];
+        hipLaunchKernelGGL(k_bwd_pair<T>, dim3(1 + (c1 - c0)), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b, k, w->lpair + c0);
+      }
+    };
+    const char *tc_env = getenv("BA_SPARSE_TWO_RUNS");  // (read per call: a test compares the sweeps in one process)
+    int c_hi = pat->split + pat->b_clean;
+    if (c_hi > 0 && 2 * c_hi - 1 >= nt) c_hi--;  // (a last single row stays with the rows behind the groups)
+    const char *b2_env = getenv("BA_SPARSE_BWD2");
+    if (pat->split > 0 && c_hi > pat->split && !(tc_env && tc_env[0] == '0') && !(b2_env && b2_env[0] == '0')) {
+      for (int q = npairs - 1; q >= c_hi; q--) single(q);
+      const int both = std::min(pat->split, c_hi - pat->split);
+      for (int i = 0; i < both; i++) {
+        const int qa = pat->split - 1 - i, qc = c_hi - 1 - i;
+        const int a0 = pat->lpair_ptr[(size_t)qa], a1 = pat->lpair_ptr[(size_t)qa + 1];
+        const int c0 = pat->lpair_ptr[(size_t)qc], c1 = pat->lpair_ptr[(size_t)qc + 1];
+        hipLaunchKernelGGL(k_bwd_pair2<T>, dim3(2 + (a1 - a0) + (c1 - c0)), dim3(256), 0, st, w->S, w->col_off, w->Linv, w->D, y, d_b,
+                           2 * qa + 1, w->lpair + a0, 1 + (a1 - a0), 2 * qc + 1, w->lpair + c0);
+      }
+      for (int q = pat->split - 1 - both; q >= 0; q--) single(q);
+      for (int q = c_hi - 1 - both; q >= pat->split; q--) single(q);
+    } else {
+      for (int q = npairs - 1; q >= 0; q--) single(q);
     }
     BA_HIP_CHECK(hipGetLastError());
     return BA_OK;

@@ -599,12 +599,14 @@ void tile_pattern_build(int64_t nt, std::vector<unsigned char> &occ /* nt x nt, 
       }
     out->lcol_ptr.push_back((int)out->lcol.size());
   }
-  // backward sweep two tile rows per launch (rows k, k-1 for k = nt-1, nt-3, ...): the union of their pattern columns < k-1
+  // backward sweep, the two tile rows of a tile column pair per launch (rows 2q + 1, 2q; a last single row when nt is odd takes
+  // its lcol list): the union of their pattern columns < 2q
   out->lpair_ptr.assign(1, 0);
   out->lpair.clear();
-  for (int64_t k = nt - 1; k >= 1; k -= 2) {
-    for (int64_t j = 0; j < k - 1; j++)
-      if (occ[(size_t)(k * nt + j)] || occ[(size_t)((k - 1) * nt + j)]) out->lpair.push_back((int)j);
+  for (int64_t q = 0; q < npairs; q++) {
+    const int64_t k0 = 2 * q, k1 = 2 * q + 1;
+    for (int64_t j = 0; j < k0; j++)
+      if (occ[(size_t)(k0 * nt + j)] || (k1 < nt && occ[(size_t)(k1 * nt + j)])) out->lpair.push_back((int)j);
     out->lpair_ptr.push_back((int)out->lpair.size());
   }
   out->tile_fill = (double)(ntiles + nt) / ((double)nt * (double)(nt + 1) / 2);

@@ -13,7 +13,7 @@ struct TilePattern {
   int64_t nt = 0;
   std::vector<int> prow_ptr, prow;  // pair q: [k+1] + the tile rows of its pattern (k = 2q), ascending
   std::vector<int> lcol_ptr, lcol;  // tile row i: the tile columns j < i of its pattern, ascending
-  std::vector<int> lpair_ptr, lpair;  // launch q of the paired backward sweep (rows k = nt-1-2q, k-1): union of their columns < k-1
+  std::vector<int> lpair_ptr, lpair;  // pair q of the backward sweep (tile rows 2q + 1, 2q): union of their pattern columns < 2q
   double tile_fill = 1.0;           // pattern tiles (with fill) / all lower tiles
   double flop_fill = 1.0;           // trailing-update tiles of the pattern / of the dense factorisation
   // Two independent chains (elimination from both ends of a profile-ordered sequence, see cam_order): the pairs [0, a_clean)
