@@ -679,7 +679,7 @@ __device__ inline void tile_gemm_abt_priv(const T *__restrict__ A0, const T *__r
                                           const T *__restrict__ B3 = nullptr) {
   typedef typename PV<T>::vu vu;
   constexpr int PKC = PV<T>::KC, PLDK = PV<T>::LDK, VL = PV<T>::VL;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3;  // (& 3: a workgroup of eight waves works on two tiles)
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
   const int fr = lane & 15, fk = lane >> 4;
   T *sA = lds + wv * (2 * 64 * PLDK), *sB = sA + 64 * PLDK;
@@ -1274,7 +1274,7 @@ __device__ __forceinline__ void ldl_update_tile(T *__restrict__ S, const int64_t
                         V1 + (int64_t)i * NB * NB, Lp1 ? Lp1 + (int64_t)j * NB * NB : S + tix(co, j, k + 1) * NB * NB, lds, acc);
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));  // keep the epilogue's address arithmetic out of the main loop's live ranges
-  const int lane = tid2 & 63, wv = tid2 >> 6;
+  const int lane = tid2 & 63, wv = (tid2 >> 6) & 3;
   const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
   // epilogue: the 64 values of a lane are read-modify-written in two batches of 32 so that 32 loads are in flight at once
   T *cbase = Sij + wr * NB + wc + (lane & 15);
@@ -1384,13 +1384,18 @@ __global__ __launch_bounds__(256, 2) void k_ldl_update(T *__restrict__ S, const 
 // over.  So this form keeps to a part of the chip: a fixed number of workgroups (grid), each asking for more than half a
 // CU's LDS so that no two share a CU, walking the tiles t = block, block + grid, ...; the CUs it leaves alone take the
 // chain.  Same tile routine, same enumeration (triangular index over the row list): same bits as k_ldl_update.
-constexpr size_t PART_LDS_BYTES = 84 * 1024;
+// Eight waves per workgroup: its two halves walk the tiles independently (nothing in the tile routine synchronises beyond the
+// wave), so that a CU runs two waves per SIMD as under k_ldl_update -- with four waves (first version) a CU of the rest did
+// 60 % of the work it does under the full launch.
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_update_part(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
+constexpr size_t part_lds_bytes() { return 2 * gemm_priv_lds_bytes<T>(); }  // 147 KB: one workgroup per CU
+template <typename T>
+__global__ __launch_bounds__(512) void k_ldl_update_part(T *__restrict__ S, const int64_t *__restrict__ co, const T *__restrict__ V0,
                                                           const T *__restrict__ V1, int k, int nblk, const int *__restrict__ rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-  T *lds = reinterpret_cast<T *>(smraw);
-  for (int t = blockIdx.x; t < nblk; t += gridDim.x) {
+  const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  T *lds = reinterpret_cast<T *>(smraw + half * gemm_priv_lds_bytes<T>());
+  for (int t = 2 * blockIdx.x + half; t < nblk; t += 2 * gridDim.x) {
     int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
     while (ii * (ii + 1) / 2 > t) ii--;
@@ -1401,11 +1406,12 @@ __global__ __launch_bounds__(256) void k_ldl_update_part(T *__restrict__ S, cons
 
 // k_ldl_update_part for two runs: the rests of both runs' updates walked by one set of persistent workgroups
 template <typename T>
-__global__ __launch_bounds__(256) void k_ldl_update_part2(T *__restrict__ S, const int64_t *__restrict__ co, RunPanel<T> a, int nblk_a,
+__global__ __launch_bounds__(512) void k_ldl_update_part2(T *__restrict__ S, const int64_t *__restrict__ co, RunPanel<T> a, int nblk_a,
                                                            RunPanel<T> c, int nblk_c, int64_t panel) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-  T *lds = reinterpret_cast<T *>(smraw);
-  for (int tt = blockIdx.x; tt < nblk_a + nblk_c; tt += gridDim.x) {
+  const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  T *lds = reinterpret_cast<T *>(smraw + half * gemm_priv_lds_bytes<T>());
+  for (int tt = 2 * blockIdx.x + half; tt < nblk_a + nblk_c; tt += 2 * gridDim.x) {
     const bool second = tt >= nblk_a;
     const RunPanel<T> &r = second ? c : a;
     const int t = tt - (second ? nblk_a : 0);
@@ -1646,9 +1652,9 @@ static int set_kernel_attrs() {
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_diag2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(DIAG_LDS_ELEMS * sizeof(T))));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_part2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)PART_LDS_BYTES));
+                                   (int)part_lds_bytes<T>()));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update_part<T>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes<T>()));
   BA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldl_update<T, 1, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_priv_lds_bytes<T>()));
   g_attr_done.store(true);
@@ -2247,7 +2253,7 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
         BA_HIP_CHECK(hipStreamWaitEvent(w->rest, w->ev_recv[slot], 0));
         const RunPanel<T> qa2 = panel_of(ka, VA, w->prow + la + 1 + nla), qb2 = panel_of(kb, VB, w->prow + lb + 1 + nlb);
         const int ntile = rest_a + rest_b;
-        hipLaunchKernelGGL(k_ldl_update_part2<T>, dim3(ntile < rest_cus ? ntile : rest_cus), dim3(256), PART_LDS_BYTES, w->rest, w->S, w->col_off,
+        hipLaunchKernelGGL(k_ldl_update_part2<T>, dim3((ntile + 1) / 2 < rest_cus ? (ntile + 1) / 2 : rest_cus), dim3(512), part_lds_bytes<T>(), w->rest, w->S, w->col_off,
                            qa2, rest_a, qb2, rest_b, panel);
         BA_HIP_CHECK(hipEventRecord(w->ev_upd[slot], w->rest));
         pending[slot] = true;
@@ -2299,7 +2305,7 @@ int dense_ldl_factor_sparse(ba_problem *p, DenseLDLT<T> *w, hipStream_t st, int 
       BA_HIP_CHECK(hipStreamWaitEvent(w->rest, w->ev_recv[slot], 0));
       {
         const int nblk = nrest * (nrest + 1) / 2;
-        hipLaunchKernelGGL(k_ldl_update_part<T>, dim3(nblk < rest_cus ? nblk : rest_cus), dim3(256), PART_LDS_BYTES, w->rest, w->S, w->col_off,
+        hipLaunchKernelGGL(k_ldl_update_part<T>, dim3((nblk + 1) / 2 < rest_cus ? (nblk + 1) / 2 : rest_cus), dim3(512), part_lds_bytes<T>(), w->rest, w->S, w->col_off,
                            V0, V1, k, nblk, rows2 + nlead);
       }
       BA_HIP_CHECK(hipEventRecord(w->ev_upd[slot], w->rest));
