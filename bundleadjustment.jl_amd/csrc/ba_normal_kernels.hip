@@ -410,8 +410,12 @@ constexpr int SCHUR_RING = SCHUR_PF * SCHUR_SLOT;     // doubles per wave
 // register whose load is in flight makes the compiler wait for that load, so the generated loop began with s_waitcnt
 // vmcnt(0): every trip waited for the loads issued one trip earlier -- a whole memory round trip, ~4 700 cycles per task
 // pair and wave in the kernel trace -- whatever the depth of the ring; which is why depths 2, 3, 4 had measured the same.)
-__device__ inline d4s schur_accumulate(int t_begin, int t_end, const int *__restrict__ task_a, const int *__restrict__ task_b,
-                                       const double *__restrict__ J, const double *__restrict__ Y, double *ring) {
+// PRE: the observation indices of the first 64 tasks come in registers (pre_oa / pre_ob: lane l holds task t_begin + l) --
+// k_schur_blocks loads them one key ahead, so that a key does not start with a memory round trip for its own task list.
+template <bool PRE = false>
+__device__ __forceinline__ d4s schur_accumulate(int t_begin, int t_end, const int *__restrict__ task_a, const int *__restrict__ task_b,
+                                                const double *__restrict__ J, const double *__restrict__ Y, double *ring,
+                                                int pre_oa = 0, int pre_ob = 0) {
   const int lane = threadIdx.x & 63;
   const int fr = lane & 15, fk = lane >> 4, tl = fk >> 1, al = fk & 1;
   d4s acc = {0, 0, 0, 0};
@@ -429,7 +433,10 @@ __device__ inline d4s schur_accumulate(int t_begin, int t_end, const int *__rest
   for (int c0t = t_begin; c0t < t_end; c0t += 64) {
     const int nin = (t_end - c0t) < 64 ? (t_end - c0t) : 64;
     int my_oa = 0, my_ob = 0;
-    if (lane < nin) {
+    if (PRE && c0t == t_begin) {
+      my_oa = pre_oa;
+      my_ob = pre_ob;
+    } else if (lane < nin) {
       my_oa = task_a[c0t + lane];
       my_ob = task_b[c0t + lane];
     }
@@ -487,7 +494,7 @@ __device__ inline void schur_store_block(double *S, const int64_t *__restrict__ 
 }
 
 // one wave per key; keys longer than split_above tasks (> 0) are left to k_schur_chunks / k_schur_combine
-__global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *__restrict__ key_ptr,
+__global__ __launch_bounds__(BLK, 6) void k_schur_blocks(int64_t nkeys, const int *__restrict__ key_ptr,
                                                        const int *__restrict__ key_ca, const int *__restrict__ key_cb,
                                                        const int *__restrict__ task_a, const int *__restrict__ task_b,
                                                        const double *__restrict__ J, const double *__restrict__ Y,
@@ -508,19 +515,75 @@ __global__ __launch_bounds__(BLK) void k_schur_blocks(int64_t nkeys, const int *
   // re-read from that XCD's L2 -- 4.3 -> 5.1 ms on Venice in round 1's kernel, 3.73 -> 3.67 ms in this one: the L2-miss traffic
   // (9.5 GB per launch against 3.4 GB if every row were fetched once per XCD that needs it) is served by the MALL and does not
   // bound the kernel; the interleaved order stays.)
-  for (int64_t kq = (int64_t)blockIdx.x * (BLK / 64) + wv; kq < nkeys; kq += (int64_t)gridDim.x * (BLK / 64)) {
-    const int64_t key = klist ? klist[kq] : kq;
-    const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
-    if (split_above > 0 && t_end - t_begin > split_above) continue;
-    const d4s acc = schur_accumulate(t_begin, t_end, task_a, task_b, J, Y, ring[wv]);
-    const int ca = key_ca[key], cb = key_cb[key];
-    if (fr < 9) {
+  // (the wave's key index is uniform: told so, the compiler reads the key tables through the scalar cache into scalar registers)
+  const int64_t stride = (int64_t)gridDim.x * (BLK / 64), first = (int64_t)blockIdx.x * (BLK / 64) + __builtin_amdgcn_readfirstlane(wv);
+  if (klist) {  // (chunked assembly of a distributed run: the keys come through a list -- one more dependent load; plain loop)
+    for (int64_t kq = first; kq < nkeys; kq += stride) {
+      const int64_t key = klist[kq];
+      const int t_begin = key_ptr[key], t_end = key_ptr[key + 1];
+      if (split_above > 0 && t_end - t_begin > split_above) continue;
+      const d4s acc = schur_accumulate(t_begin, t_end, task_a, task_b, J, Y, ring[wv]);
+      const int ca = key_ca[key], cb = key_cb[key];
+      if (fr < 9) {
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int i = fk + 4 * g;
-        if (i < 9) schur_store_block(S, co, ca, cb, Hcc, lambda, damp_c, i, fr, acc[g], cam_of);
+        for (int g = 0; g < 4; g++) {
+          const int i = fk + 4 * g;
+          if (i < 9) schur_store_block(S, co, ca, cb, Hcc, lambda, damp_c, i, fr, acc[g], cam_of);
+        }
       }
     }
+    return;
+  }
+  // A key is ~10 tasks on Venice: five trips of the ring between three dependent memory round trips (its range in key_ptr,
+  // its task list, its first records), and the counters show the waves parked on s_waitcnt 70 % of their cycles.  So the
+  // wave runs one key AHEAD with its lists: while key i is summed the task list of key i + 1 is in flight (and the range of
+  // key i + 2, which that load needs), and a key starts with its record loads.  (A load issued BEFORE the ring's loads is
+  // older than they are: the hand-counted vmcnt waits of the ring stay valid.)
+  // (what is wave-uniform moves to scalar registers once it has arrived: five waves per SIMD with everything in vector
+  // registers, six as before with this)
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto list_of = [&](int tb, int te, int &oa, int &ob) {
+    oa = ob = 0;
+    if (lane < te - tb) {  // (at most the first 64 tasks: what the first trip of schur_accumulate needs)
+      oa = task_a[tb + lane];
+      ob = task_b[tb + lane];
+    }
+  };
+  int tb0 = 0, te0 = 0, ca0 = 0, cb0 = 0, tb1 = 0, te1 = 0, oa0, ob0;
+  if (first < nkeys) {
+    tb0 = uni(key_ptr[first]);
+    te0 = uni(key_ptr[first + 1]);
+    ca0 = uni(key_ca[first]);
+    cb0 = uni(key_cb[first]);
+  }
+  if (first + stride < nkeys) {
+    tb1 = uni(key_ptr[first + stride]);
+    te1 = uni(key_ptr[first + stride + 1]);
+  }
+  list_of(tb0, te0, oa0, ob0);
+  for (int64_t kq = first; kq < nkeys; kq += stride) {
+    int tb2 = 0, te2 = 0, ca1 = 0, cb1 = 0, oa1, ob1;  // in flight while key kq is summed
+    if (kq + 2 * stride < nkeys) {
+      tb2 = key_ptr[kq + 2 * stride];
+      te2 = key_ptr[kq + 2 * stride + 1];
+    }
+    if (kq + stride < nkeys) {
+      ca1 = key_ca[kq + stride];
+      cb1 = key_cb[kq + stride];
+    }
+    list_of(tb1, te1, oa1, ob1);
+    if (!(split_above > 0 && te0 - tb0 > split_above)) {
+      const d4s acc = schur_accumulate<true>(tb0, te0, task_a, task_b, J, Y, ring[wv], oa0, ob0);
+      if (fr < 9) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int i = fk + 4 * g;
+          if (i < 9) schur_store_block(S, co, ca0, cb0, Hcc, lambda, damp_c, i, fr, acc[g], cam_of);
+        }
+      }
+    }
+    tb0 = tb1; te0 = te1; oa0 = oa1; ob0 = ob1;
+    ca0 = uni(ca1); cb0 = uni(cb1); tb1 = uni(tb2); te1 = uni(te2);
   }
 }
 
