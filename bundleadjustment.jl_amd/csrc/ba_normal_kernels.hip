@@ -462,11 +462,14 @@ __device__ __forceinline__ d4s schur_accumulate(int t_begin, int t_end, const in
         const double *sg = ring + q * SCHUR_SLOT + 64 * tl;
         const bool on = (fr < 9) && (2 * pr + tl < nin);
         const int fi = fr < 9 ? fr : 0;
+        // (every operand is read unconditionally -- the addresses are valid in every lane -- and masked afterwards: as
+        // `on ? sg[..] : 0` the reads sat in branches of their own, three LDS round trips in sequence per trip)
         const double a0 = sg[12 * al], a1 = sg[12 * al + 1], a2 = sg[12 * al + 2];
+        const double av = sg[12 * al + 3 + fi], b0 = sg[25 + fi], b1 = sg[35 + fi];
         const double q0 = a0 * sg[44] + a1 * sg[46] + a2 * sg[48];
         const double q1 = a0 * sg[45] + a1 * sg[47] + a2 * sg[49];
-        const double aop = on ? sg[12 * al + 3 + fi] : 0.0;
-        const double bop = on ? q0 * sg[25 + fi] + q1 * sg[35 + fi] : 0.0;
+        const double aop = on ? av : 0.0;
+        const double bop = on ? q0 * b0 + q1 * b1 : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
         // the slot is free once its operands are in registers (the matrix instruction above has them): refill it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -1,5 +1,5 @@
 set -e
-TAG=r04_g
+TAG=${TAG:-r04_h}
 bash tools/round_profiles.sh $TAG
 b() { name=$1; shift; python bench.py --cpu-seconds 0 --no-pcg "$@" > gpurun_out/${TAG}_bench_$name.json 2> gpurun_out/${TAG}_bench_$name.err; python -c "import sys,json; d=json.loads(open('gpurun_out/${TAG}_bench_$name.json').read().strip().splitlines()[-1]); print('$name', round(d['value'],2), round(d['ms_per_step'],2), d.get('schur_pattern',{}).get('camera_sequence'))"; }
 b venice_locality013 --locality 0.13
