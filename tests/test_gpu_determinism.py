@@ -69,16 +69,18 @@ def test_lm_step_twice_same_bits_venice_scaled(ba, gpu_ok):
 
 
 
-@pytest.mark.parametrize("shuffle", [False, True])
-def test_block_sparse_two_chains(ba, orc, gpu_ok, shuffle):
+@pytest.mark.parametrize("ncams,shuffle", [(1100, False), (1100, True), (1095, False)])
+def test_block_sparse_two_chains(ba, orc, gpu_ok, ncams, shuffle):
     """A profile eliminated from both ends (ba_order.cpp: "two-ended"): the list schedule runs the two independent runs of tile
     column pairs together, pair i of either run in the same launches (dense_ldl_factor_sparse, "two runs per launch"), and the
     remaining pairs in order.  1 100 cameras (n =
     9 900, 78 tile rows), cameras of a point within 10 % of the cameras, as generated and renumbered at random: the sequence
     chosen is the two-ended one, the pattern reports two runs, the step equals the oracle's (its ldl_analyse handed the same
     camera sequence) to 1e-9 and the one-chain schedule's (BA_SPARSE_TWO_RUNS=0) to 1e-11, Float32 to Float32 level; the
-    same bits twice, and recorded graphs = plain launches."""
-    p = ba.synthetic.make_problem(1100, 6000, 30000, seed=35, locality=0.1)
+    same bits twice, and recorded graphs = plain launches.  The backward sweep takes the row pairs of the two groups in one
+    launch (k_bwd_pair2): the same bits as one pair per launch (BA_SPARSE_BWD2=0).  1 095 cameras: 77 tile rows -- an ODD
+    number, the sweep starts with a single row and the forward pairs stay aligned (the Final-13682 shape has 963)."""
+    p = ba.synthetic.make_problem(ncams, 6000, 30000, seed=35, locality=0.1)
     if shuffle:
         p, _ = ba.synthetic.shuffle_cameras(p, seed=8)
     arrays = ba.synthetic.as_arrays(p)
@@ -100,6 +102,11 @@ def test_block_sparse_two_chains(ba, orc, gpu_ok, shuffle):
     n1, _, _, _, _, _, _ = _env("BA_SPARSE_LOOKAHEAD", "0", step)
     l32, _, _, _, _, _, _ = _env("BA_SPARSE_LOOKAHEAD_MIN", "1", lambda: step(np.float32))
     n32, _, _, _, _, _, _ = _env("BA_SPARSE_LOOKAHEAD", "0", lambda: step(np.float32))
+    w1, _, _, _, _, _, _ = _env("BA_SPARSE_BWD2", "0", step)
+    w32, _, _, _, _, _, _ = _env("BA_SPARSE_BWD2", "0", lambda: step(np.float32))
+    for tag, (x, y) in {"backward sweep, two groups per launch vs one pair per launch": (a1, w1), "Float32: the same": (f1, w32)}.items():
+        rep = bits_report(x, y, tag)
+        assert not rep, rep
     for tag, (x, y) in {"two runs with look-ahead, twice": (l1, l2), "two runs, look-ahead vs in order": (l1, n1),
                         "two runs, look-ahead forced vs default threshold": (l1, a1), "Float32: look-ahead vs in order": (l32, n32)}.items():
         rep = bits_report(x, y, tag)
