@@ -542,12 +542,17 @@ def test_loopback_reduce_scatter_assembly_equals_reduce_onto_owner(ba, loopback,
         assert staging <= 0.5 * biggest + 2 * nt + 2, f"staging {staging} tiles, largest share {biggest}, {nt} tile rows"
 
 
-def test_loopback_camera_ordering_on_several_ranks(ba, loopback):
+@pytest.mark.parametrize("scene", ["band", "plane"])
+def test_loopback_camera_ordering_on_several_ranks(ba, loopback, scene):
     """A randomly numbered block-banded problem on 3 ranks: every rank sees only the camera pairs ITS points connect; the
     camera graph is summed over the ranks before it is ordered, so every handle arrives at the sequence (and the pattern)
-    of the one-rank handle, takes the list schedule, and the step is the one-rank step."""
-    p0 = ba.synthetic.make_problem(520, 5200, 26000, seed=13, locality=0.12)
-    prob, _ = ba.synthetic.shuffle_cameras(p0, seed=6)
+    of the one-rank handle, takes the list schedule, and the step is the one-rank step.  scene = plane: cameras standing in
+    the plane (a two-dimensional geometric camera graph, irregular row lists) instead of a band."""
+    if scene == "band":
+        p0 = ba.synthetic.make_problem(520, 5200, 26000, seed=13, locality=0.12)
+        prob, _ = ba.synthetic.shuffle_cameras(p0, seed=6)
+    else:
+        prob = ba.synthetic.make_problem(520, 5200, 26000, seed=14, plane_radius=0.11)
     ref = ba.BALNLPModel(arrays=ba.synthetic.as_arrays(prob))
     d_ref, half_ref, _ = ba.lm_step(ref, prob["x0"], 10.0)
     pat_ref, (perm_ref, name_ref) = ba.schur_pattern(ref), ba.schur_ordering_used(ref)
